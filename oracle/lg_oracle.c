@@ -1,0 +1,475 @@
+/*
+ * lg_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the serial / integer pieces of the reference's grasp
+ * scoring hot path whose arithmetic lives in OpenCV 4.10.0.84 (a pinned
+ * dependency of the reference, requirements.txt:9, which is NOT present in
+ * this container or on the GPU box).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.  The product path
+ * (leaf-grasping-vision-ml_amd/csrc) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned vs real OpenCV" for every function in this
+ * file.  The reference holds no fixture for these boundaries;
+ * each function restates the library's published algorithm and is anchored on
+ * the reference's own call sites, cited per function.  Self-consistency
+ * checks (brute-force Dijkstra chamfer, brute-force dilation, ...) live in
+ * tests/test_oracle_c.py.
+ *
+ * Build: make -C oracle   (gcc -O2 -shared -fPIC)
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LG_DIST_SHIFT 16
+#define LG_INIT_DIST0 (INT_MAX >> 2)
+
+static unsigned lg_flt_to_fix(float x) {
+    /* OpenCV CV_FLT_TO_FIX(x,n) = cvRound(x * (1 << n)); float*int is a float
+       product (exact: power of two), cvRound = round-half-even. */
+    float p = x * (float)(1 << LG_DIST_SHIFT);
+    return (unsigned)lrintf(p);
+}
+
+/*
+ * Chamfer distance transform, cv2.distanceTransform(src, DIST_L2, 3 or 5).
+ * Call sites: grasp_point_selector.py:266 (L2,5 distance_map), :529-530
+ * (L2,5 dist_inside / dist_outside), :611,:616 (L2,3 isolation).
+ * Algorithm restated from OpenCV imgproc distransform.cpp
+ * (distanceTransform_3x3 / _5x5): 16.16 fixed point, two raster passes over a
+ * temp image padded by BORDER cells initialised to INIT_DIST0 = INT_MAX>>2,
+ * weights L2/3 = (0.955, 1.3693), L2/5 = (1, 1.4, 2.1969).
+ * src: H*W bytes, nonzero = inside (distance to nearest zero pixel).
+ * fix_out (optional): the final fixed-point integers.
+ */
+void lg_chamfer_dt(const uint8_t* src, int H, int W, int mask_size, float* dst,
+                   uint32_t* fix_out) {
+    const int BORDER = (mask_size == 3) ? 1 : 2;
+    const unsigned HV = (mask_size == 3) ? lg_flt_to_fix(0.955f) : lg_flt_to_fix(1.0f);
+    const unsigned DG = (mask_size == 3) ? lg_flt_to_fix(1.3693f) : lg_flt_to_fix(1.4f);
+    const unsigned LG = (mask_size == 3) ? 0u : lg_flt_to_fix(2.1969f);
+    const unsigned DIST_MAX = UINT_MAX - ((mask_size == 3) ? DG : LG);
+    const float scale = 1.f / (1 << LG_DIST_SHIFT);
+    const int step = W + 2 * BORDER;
+    unsigned* temp = (unsigned*)malloc((size_t)(H + 2 * BORDER) * step * sizeof(unsigned));
+    int i, j;
+    /* initTopBottom */
+    for (i = 0; i < BORDER; i++) {
+        unsigned* top = temp + (size_t)i * step;
+        unsigned* bot = temp + (size_t)(H + 2 * BORDER - i - 1) * step;
+        for (j = 0; j < step; j++) top[j] = bot[j] = LG_INIT_DIST0;
+    }
+    /* forward pass */
+    for (i = 0; i < H; i++) {
+        const uint8_t* s = src + (size_t)i * W;
+        unsigned* tmp = temp + (size_t)(i + BORDER) * step + BORDER;
+        for (j = 0; j < BORDER; j++) tmp[-j - 1] = tmp[W + j] = LG_INIT_DIST0;
+        for (j = 0; j < W; j++) {
+            if (!s[j]) {
+                tmp[j] = 0;
+            } else if (mask_size == 3) {
+                unsigned t0 = tmp[j - step - 1] + DG;
+                unsigned t = tmp[j - step] + HV;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step + 1] + DG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - 1] + HV;
+                if (t0 > t) t0 = t;
+                tmp[j] = (t0 > DIST_MAX) ? DIST_MAX : t0;
+            } else {
+                unsigned t0 = tmp[j - step * 2 - 1] + LG;
+                unsigned t = tmp[j - step * 2 + 1] + LG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step - 2] + LG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step - 1] + DG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step] + HV;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step + 1] + DG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - step + 2] + LG;
+                if (t0 > t) t0 = t;
+                t = tmp[j - 1] + HV;
+                if (t0 > t) t0 = t;
+                tmp[j] = (t0 > DIST_MAX) ? DIST_MAX : t0;
+            }
+        }
+    }
+    /* backward pass */
+    for (i = H - 1; i >= 0; i--) {
+        float* d = dst + (size_t)i * W;
+        unsigned* tmp = temp + (size_t)(i + BORDER) * step + BORDER;
+        for (j = W - 1; j >= 0; j--) {
+            unsigned t0 = tmp[j];
+            if (t0 > HV) {
+                unsigned t;
+                if (mask_size == 3) {
+                    t = tmp[j + step + 1] + DG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step] + HV;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step - 1] + DG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + 1] + HV;
+                    if (t0 > t) t0 = t;
+                } else {
+                    t = tmp[j + step * 2 + 1] + LG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step * 2 - 1] + LG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step + 2] + LG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step + 1] + DG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step] + HV;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step - 1] + DG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + step - 2] + LG;
+                    if (t0 > t) t0 = t;
+                    t = tmp[j + 1] + HV;
+                    if (t0 > t) t0 = t;
+                }
+                tmp[j] = t0;
+            }
+            t0 = (t0 > DIST_MAX) ? DIST_MAX : t0;
+            if (fix_out) fix_out[(size_t)i * W + j] = t0;
+            d[j] = (float)(t0 * scale);
+        }
+    }
+    free(temp);
+}
+
+/*
+ * cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)).
+ * Call sites: grasp_point_selector.py:601-602 (30, 40), :696 (30), :778 (31).
+ * Restated from OpenCV imgproc morph.dispatch.cpp getStructuringElement:
+ * r = k/2, c = k/2; row i: dy = i - r, dx = round(c*sqrt((r*r-dy*dy)/(r*r))),
+ * ones in [max(c-dx,0), min(c+dx+1,k)).
+ */
+void lg_ellipse_se(int k, uint8_t* out /* k*k */) {
+    int r = k / 2, c = k / 2, i, j;
+    double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (i = 0; i < k; i++) {
+        int j1 = 0, j2 = 0, dy = i - r;
+        if (k == 1) {
+            j2 = 1;
+        } else if (abs(dy) <= r) {
+            int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1 = (c - dx > 0) ? c - dx : 0;
+            j2 = (c + dx + 1 < k) ? c + dx + 1 : k;
+        }
+        for (j = 0; j < k; j++) out[i * k + j] = (j >= j1 && j < j2) ? 1 : 0;
+    }
+}
+
+/*
+ * cv2.dilate(src, se) for a binary 0/1 image: anchor = (k/2, k/2), constant
+ * border that never wins the max.  dst(x,y) = max over se(i,j)!=0 of
+ * src(x + j - k/2, y + i - k/2).  Call sites: grasp_point_selector.py:610,
+ * :615, :699, :779.  Implemented with per-row prefix sums (span queries).
+ */
+void lg_dilate(const uint8_t* src, int H, int W, const uint8_t* se, int k, uint8_t* dst) {
+    int a = k / 2, i, j, x, y;
+    int* lo = (int*)malloc(sizeof(int) * k);
+    int* hi = (int*)malloc(sizeof(int) * k);
+    int* pre = (int*)malloc(sizeof(int) * (size_t)H * (W + 1));
+    for (i = 0; i < k; i++) {
+        lo[i] = k;
+        hi[i] = -1;
+        for (j = 0; j < k; j++)
+            if (se[i * k + j]) {
+                if (j < lo[i]) lo[i] = j;
+                if (j > hi[i]) hi[i] = j;
+            }
+        /* ellipse rows are single spans; assert-equivalent: fall back to per-pixel below if not */
+    }
+    for (y = 0; y < H; y++) {
+        int* p = pre + (size_t)y * (W + 1);
+        p[0] = 0;
+        for (x = 0; x < W; x++) p[x + 1] = p[x] + (src[(size_t)y * W + x] != 0);
+    }
+    for (y = 0; y < H; y++)
+        for (x = 0; x < W; x++) {
+            int hit = 0;
+            for (i = 0; i < k && !hit; i++) {
+                int yy = y + i - a, x0, x1;
+                if (hi[i] < 0 || yy < 0 || yy >= H) continue;
+                x0 = x + lo[i] - a;
+                x1 = x + hi[i] - a;
+                if (x0 < 0) x0 = 0;
+                if (x1 > W - 1) x1 = W - 1;
+                if (x0 > x1) continue;
+                {
+                    const int* p = pre + (size_t)yy * (W + 1);
+                    if (p[x1 + 1] - p[x0] > 0) hit = 1;
+                }
+            }
+            dst[(size_t)y * W + x] = (uint8_t)hit;
+        }
+    free(lo);
+    free(hi);
+    free(pre);
+}
+
+/* ------------------------------------------------------------------------ */
+/*
+ * External contours + min-area rectangle:
+ *   cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE) -> largest by
+ *   cv2.contourArea -> cv2.minAreaRect  (grasp_point_selector.py:722-748).
+ * Restated: Suzuki-Abe border following (8-connected foreground, outer
+ * borders), shoelace area of the traced pixel-centre polygon, convex hull,
+ * minimum-area enclosing rectangle (one side collinear with a hull edge).
+ * Returned orientation = direction of the rectangle's LONGER side in
+ * (0, 180] degrees, which is what estimate_leaf_orientation's
+ * "if size[0] < size[1]: angle += 90" yields for OpenCV>=4.5.1's (0,90]
+ * angle convention; the result is consumed modulo 180 degrees (:556-558).
+ */
+typedef struct { int x, y; } lg_pt;
+
+/* Trace the outer border that starts at (sx, sy) (a foreground pixel whose
+   left neighbour is background).  img is a padded (H+2)x(W+2) copy, 1 pixel
+   zero frame, so no bounds checks are needed.  Returns number of points. */
+static int lg_trace_outer(const uint8_t* img, int step, int sx, int sy, lg_pt* out, int cap,
+                          int8_t* visited_start) {
+    /* 8-neighbourhood in clockwise order starting from West (image coords, y down):
+       W, NW, N, NE, E, SE, S, SW */
+    static const int dx8[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+    static const int dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int n = 0, k, dir;
+    int i1x = -1, i1y = -1;
+    int cx, cy, px, py;
+    (void)visited_start;
+    /* (3.1) from the West neighbour (i2,j2)=(sx-1,sy) look clockwise for a nonzero pixel */
+    dir = 0;
+    for (k = 0; k < 8; k++) {
+        int d = (dir + k) & 7;
+        if (img[(sy + dy8[d]) * step + sx + dx8[d]]) {
+            i1x = sx + dx8[d];
+            i1y = sy + dy8[d];
+            break;
+        }
+    }
+    if (i1x < 0) { /* isolated pixel */
+        if (n < cap) { out[n].x = sx; out[n].y = sy; }
+        return 1;
+    }
+    /* (3.2) (i2,j2) <- (i1,j1), (i3,j3) <- start */
+    px = i1x; py = i1y; cx = sx; cy = sy;
+    for (;;) {
+        /* (3.3) from the neighbour after (px,py) in counter-clockwise order, find nonzero */
+        int dprev = 0, nx = cx, ny = cy, found = 0;
+        for (k = 0; k < 8; k++)
+            if (cx + dx8[k] == px && cy + dy8[k] == py) { dprev = k; break; }
+        for (k = 1; k <= 8; k++) {
+            int d = (dprev - k) & 7; /* counter-clockwise */
+            if (img[(cy + dy8[d]) * step + cx + dx8[d]]) {
+                nx = cx + dx8[d];
+                ny = cy + dy8[d];
+                found = 1;
+                break;
+            }
+        }
+        if (n < cap) { out[n].x = cx; out[n].y = cy; }
+        n++;
+        if (!found) break;
+        /* (3.5) termination: back at start and next is i1 */
+        if (nx == sx && ny == sy && cx == i1x && cy == i1y) break;
+        px = cx; py = cy; cx = nx; cy = ny;
+        if (n > 8 * cap) break; /* safety */
+    }
+    return n;
+}
+
+static double lg_cross(lg_pt o, lg_pt a, lg_pt b) {
+    return (double)(a.x - o.x) * (double)(b.y - o.y) - (double)(a.y - o.y) * (double)(b.x - o.x);
+}
+static int lg_pt_cmp(const void* a, const void* b) {
+    const lg_pt* p = (const lg_pt*)a;
+    const lg_pt* q = (const lg_pt*)b;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;
+    return 0;
+}
+/* Andrew monotone chain; returns hull size, hull in counter-clockwise order (math axes). */
+static int lg_hull(lg_pt* pts, int n, lg_pt* hull) {
+    int i, k = 0, t;
+    qsort(pts, n, sizeof(lg_pt), lg_pt_cmp);
+    if (n < 3) {
+        for (i = 0; i < n; i++) hull[i] = pts[i];
+        return n;
+    }
+    for (i = 0; i < n; i++) {
+        while (k >= 2 && lg_cross(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--;
+        hull[k++] = pts[i];
+    }
+    for (i = n - 2, t = k + 1; i >= 0; i--) {
+        while (k >= t && lg_cross(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--;
+        hull[k++] = pts[i];
+    }
+    return k - 1;
+}
+
+/*
+ * out[0]=angle_rad (long side, (0,pi]), out[1]=major, out[2]=minor,
+ * out[3]=cx, out[4]=cy, out[5]=contour area, out[6]=contour length (points).
+ * Returns 1 if a contour was found, 0 otherwise.
+ */
+int lg_leaf_orientation(const uint8_t* mask, int H, int W, double* out) {
+    const int step = W + 2;
+    uint8_t* img = (uint8_t*)calloc((size_t)(H + 2) * step, 1);
+    int32_t* lab = (int32_t*)calloc((size_t)(H + 2) * step, sizeof(int32_t));
+    int x, y, cap = 4 * (H + W) + 16, best_n = 0, nlab = 0;
+    lg_pt* cur;
+    lg_pt* best;
+    double best_area = -1.0;
+    int* stack;
+    for (y = 0; y < H; y++)
+        for (x = 0; x < W; x++) img[(y + 1) * step + x + 1] = mask[(size_t)y * W + x] ? 1 : 0;
+    /* grow cap to the number of foreground pixels * 4 (a border can revisit pixels) */
+    {
+        size_t fg = 0;
+        for (y = 0; y < H; y++)
+            for (x = 0; x < W; x++) fg += mask[(size_t)y * W + x] != 0;
+        if ((size_t)cap < 4 * fg + 16) cap = (int)(4 * fg + 16);
+    }
+    cur = (lg_pt*)malloc(sizeof(lg_pt) * cap);
+    best = (lg_pt*)malloc(sizeof(lg_pt) * cap);
+    stack = (int*)malloc(sizeof(int) * (size_t)(H + 2) * step);
+    /* raster scan: the first (top-most, then left-most) pixel of every 8-connected
+       component starts that component's outer border.  Components nested in holes are
+       traced too; they can never have the largest contour area. */
+    for (y = 1; y <= H; y++)
+        for (x = 1; x <= W; x++) {
+            int n, i, sp;
+            double a;
+            if (!img[y * step + x] || lab[y * step + x]) continue;
+            /* flood-fill label (8-connectivity) so later pixels of this component are skipped */
+            nlab++;
+            sp = 0;
+            stack[sp++] = y * step + x;
+            lab[y * step + x] = nlab;
+            while (sp) {
+                int p = stack[--sp], d;
+                static const int off8x[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+                static const int off8y[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+                for (d = 0; d < 8; d++) {
+                    int q = p + off8y[d] * step + off8x[d];
+                    if (img[q] && !lab[q]) {
+                        lab[q] = nlab;
+                        stack[sp++] = q;
+                    }
+                }
+            }
+            n = lg_trace_outer(img, step, x, y, cur, cap, 0);
+            if (n > cap) n = cap;
+            a = 0.0;
+            for (i = 0; i < n; i++) {
+                lg_pt p = cur[i ? i - 1 : n - 1], q = cur[i];
+                a += (double)p.x * q.y - (double)q.x * p.y;
+            }
+            a = fabs(a) * 0.5;
+            if (a > best_area) {
+                best_area = a;
+                best_n = n;
+                memcpy(best, cur, sizeof(lg_pt) * n);
+            }
+        }
+    free(stack);
+    free(lab);
+    free(img);
+    if (best_n == 0) {
+        free(cur);
+        free(best);
+        return 0;
+    }
+    out[5] = best_area;
+    out[6] = (double)best_n;
+    {
+        /* to image coordinates (remove the 1-pixel frame) */
+        int i, nh;
+        lg_pt* hull = cur;
+        double min_area = 1e300, bw = 0, bh = 0, bang = 0, bcx = 0, bcy = 0;
+        for (i = 0; i < best_n; i++) { best[i].x -= 1; best[i].y -= 1; }
+        nh = lg_hull(best, best_n, hull);
+        if (nh == 1) {
+            out[0] = M_PI / 2; /* w == h == 0: angle convention of a degenerate box: 90 deg */
+            out[1] = out[2] = 0;
+            out[3] = hull[0].x;
+            out[4] = hull[0].y;
+        } else {
+            for (i = 0; i < nh; i++) {
+                lg_pt p = hull[i], q = hull[(i + 1) % nh];
+                double ex = q.x - p.x, ey = q.y - p.y, len = sqrt(ex * ex + ey * ey);
+                double ux, uy, smin = 1e300, smax = -1e300, tmin = 1e300, tmax = -1e300, area;
+                int j;
+                if (len == 0) continue;
+                ux = ex / len;
+                uy = ey / len;
+                for (j = 0; j < nh; j++) {
+                    double s = hull[j].x * ux + hull[j].y * uy;
+                    double t = -hull[j].x * uy + hull[j].y * ux;
+                    if (s < smin) smin = s;
+                    if (s > smax) smax = s;
+                    if (t < tmin) tmin = t;
+                    if (t > tmax) tmax = t;
+                }
+                area = (smax - smin) * (tmax - tmin);
+                if (area < min_area) {
+                    double sc = 0.5 * (smin + smax), tc = 0.5 * (tmin + tmax);
+                    min_area = area;
+                    bw = smax - smin; /* extent along the edge direction */
+                    bh = tmax - tmin;
+                    bang = atan2(uy, ux);
+                    bcx = sc * ux - tc * uy;
+                    bcy = sc * uy + tc * ux;
+                }
+                if (nh == 2) break;
+            }
+            {
+                double ang = (bw < bh) ? bang + M_PI / 2 : bang; /* long-side direction */
+                ang = fmod(ang, M_PI);
+                if (ang <= 0) ang += M_PI; /* (0, pi] */
+                out[0] = ang;
+                out[1] = bw > bh ? bw : bh;
+                out[2] = bw > bh ? bh : bw;
+                out[3] = bcx;
+                out[4] = bcy;
+            }
+        }
+    }
+    free(cur);
+    free(best);
+    return 1;
+}
+
+/*
+ * Greedy spaced top-k, GraspPointSelector._get_candidate_points
+ * (grasp_point_selector.py:447-482) given the full descending order.
+ * order: flat indices sorted by descending score (ties resolved by the caller);
+ * accepts idx iff no used flag in its clipped (2*md+1)^2 window, then marks it.
+ */
+int lg_greedy_nms(const int64_t* order, int64_t n, int H, int W, int top_k, int md, int32_t* out_xy) {
+    uint8_t* used = (uint8_t*)calloc((size_t)H * W, 1);
+    int cnt = 0;
+    int64_t t;
+    for (t = 0; t < n && cnt < top_k; t++) {
+        int y = (int)(order[t] / W), x = (int)(order[t] % W);
+        int y0 = y - md < 0 ? 0 : y - md, y1 = y + md + 1 > H ? H : y + md + 1;
+        int x0 = x - md < 0 ? 0 : x - md, x1 = x + md + 1 > W ? W : x + md + 1;
+        int yy, xx, any = 0;
+        for (yy = y0; yy < y1 && !any; yy++)
+            for (xx = x0; xx < x1; xx++)
+                if (used[(size_t)yy * W + xx]) { any = 1; break; }
+        if (any) continue;
+        out_xy[2 * cnt] = x;
+        out_xy[2 * cnt + 1] = y;
+        cnt++;
+        for (yy = y0; yy < y1; yy++) memset(used + (size_t)yy * W + x0, 1, (size_t)(x1 - x0));
+    }
+    free(used);
+    return cnt;
+}

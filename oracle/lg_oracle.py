@@ -1,0 +1,667 @@
+"""
+CPU ORACLE for the grasp-scoring hot path -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product (leaf-grasping-vision-ml_amd/) never imports it and
+fails loudly when its HIP library is missing.
+
+What it is: a NumPy (+ plain C, oracle/lg_oracle.c) restatement of the reference's
+per-pixel scoring path, written from the reference source text, each function
+citing the reference file:line it follows (paths relative to /root/reference).
+dtypes follow the reference step by step (float64 planes, float32 distance
+transforms / flatness) so the timing of the cpu_baseline leg is the same work.
+
+Parity status
+  * pinned by reference-generated golden vectors (tests/golden/, made by
+    tests/golden/make_golden.py importing the reference in the build container):
+    accessibility, approach, flatness, valid regions, candidate points, patch
+    extraction, GraspPointCNN forward, ML post-transform, camera/3-D math,
+    visibility score, HybridSelector / ConfidenceManager.
+  * "parity unpinned" (third-party arithmetic absent from this image, no fixture
+    in the reference): every cv2.* boundary (chamfer distanceTransform, ellipse
+    dilate, findContours/minAreaRect) -- restated in lg_oracle.c from OpenCV
+    4.10's published algorithms; skfmm.distance (replaced by an exact Euclidean
+    distance transform, see clutter_extrema); paretoset (restated O(n^2)).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build_c(force: bool = False) -> str:
+    """Compile oracle/lg_oracle.c -> oracle/_build/liblg_oracle.so (gcc)."""
+    out_dir = os.path.join(_HERE, "_build")
+    so = os.path.join(out_dir, "liblg_oracle.so")
+    src = os.path.join(_HERE, "lg_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src, "-lm"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build_c())
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.lg_chamfer_dt.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
+        L.lg_chamfer_dt.restype = None
+        L.lg_ellipse_se.argtypes = [ctypes.c_int, u8p]
+        L.lg_dilate.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int, u8p]
+        L.lg_leaf_orientation.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.lg_leaf_orientation.restype = ctypes.c_int
+        L.lg_greedy_nms.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+        L.lg_greedy_nms.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+# --------------------------------------------------------------------------- cv2 stand-ins
+def distance_transform(src_u8, mask_size=5, return_fix=False):
+    """cv2.distanceTransform(src, cv2.DIST_L2, mask_size) -> float32 [H,W]  (lg_oracle.c)."""
+    a, p = _u8(src_u8)
+    H, W = a.shape
+    out = np.empty((H, W), np.float32)
+    fix = np.empty((H, W), np.uint32)
+    _lib().lg_chamfer_dt(p, H, W, int(mask_size), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                         fix.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    return (out, fix) if return_fix else out
+
+
+def ellipse_se(k):
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)) -> uint8 [k,k]."""
+    se = np.empty((k, k), np.uint8)
+    _lib().lg_ellipse_se(int(k), se.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return se
+
+
+def dilate(src_u8, se):
+    """cv2.dilate(src, se) for 0/1 images."""
+    a, p = _u8(src_u8)
+    s, sp = _u8(se)
+    out = np.empty_like(a)
+    _lib().lg_dilate(p, a.shape[0], a.shape[1], sp, s.shape[0], out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return out
+
+
+def leaf_orientation_raw(mask_u8):
+    """findContours(EXTERNAL, NONE) -> max contourArea -> minAreaRect; see lg_oracle.c."""
+    a, p = _u8(mask_u8)
+    out = (ctypes.c_double * 8)()
+    ok = _lib().lg_leaf_orientation(p, a.shape[0], a.shape[1], out)
+    return None if not ok else [out[i] for i in range(7)]
+
+
+# --------------------------------------------------------------------------- image_processor.py
+def gaussian_kernel(size=5):
+    """ImageProcessor._create_gaussian_kernel (scripts/utils/image_processor.py:25-32)."""
+    sigma = size / 6.0
+    center = size // 2
+    x, y = np.meshgrid(np.arange(size), np.arange(size))
+    kernel = np.exp(-((x - center) ** 2 + (y - center) ** 2) / (2 * sigma ** 2))
+    kernel = kernel / kernel.sum()
+    return kernel.astype(np.float32)
+
+
+SOBEL_X = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], np.float32)  # image_processor.py:19
+SOBEL_Y = SOBEL_X.T.copy()  # image_processor.py:21
+
+
+def _xcorr_valid_f32(padded, k):
+    """F.conv2d (cross-correlation, no padding) of one float32 plane, float32 accumulate."""
+    kh, kw = k.shape
+    H = padded.shape[0] - kh + 1
+    W = padded.shape[1] - kw + 1
+    acc = np.zeros((H, W), np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            if k[i, j] != 0:
+                acc += np.float32(k[i, j]) * padded[i:i + H, j:j + W]
+    return acc
+
+
+def smooth_depth(depth_f32, gaussian_size=5):
+    """ImageProcessor.smooth_depth (image_processor.py:56-64): reflect pad g//2, 5x5 Gaussian."""
+    g = gaussian_kernel(gaussian_size)
+    p = gaussian_size // 2
+    padded = np.pad(np.asarray(depth_f32, np.float32), p, mode="reflect")
+    return _xcorr_valid_f32(padded, g)
+
+
+def flatness_map(depth_times_mask_f32, gaussian_size=5):
+    """GraspPointSelector._calculate_flatness_map (grasp_point_selector.py:635-657)."""
+    g = smooth_depth(depth_times_mask_f32, gaussian_size)
+    padded = np.pad(g, 1, mode="reflect")
+    dx = _xcorr_valid_f32(padded, SOBEL_X)
+    dy = _xcorr_valid_f32(padded, SOBEL_Y)
+    mag = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+    return np.exp(-mag * np.float32(5.0), dtype=np.float32)
+
+
+# --------------------------------------------------------------------------- grasp_point_selector.py
+class RefGraspPointSelector:
+    """Restatement of scripts/utils/grasp_point_selector.py::GraspPointSelector (CV maps, candidates,
+    CNN rescoring loop, 3-D back-projection, pre-grasp).  numpy in, numpy out."""
+
+    def __init__(self, cnn=None, gaussian_size=5):
+        self.camera_cx = 707  # grasp_point_selector.py:29-31
+        self.camera_cy = 494
+        self.f_norm = None
+        self.min_edge_distance = 20  # :25
+        self.gaussian_size = gaussian_size  # leaf_grasp_node_v3.py:37
+        self.cnn = cnn  # callable [B,9,32,32] float32 -> [B] logits, or None (= no best_model.pth, :52-54)
+
+    # :145-150
+    def set_camera_params(self, P):
+        self.f_norm = P[0, 0]
+        self.camera_cx = P[0, 2]
+        self.camera_cy = P[1, 2]
+        self.baseline = -P[0, 3] / self.f_norm
+
+    # :502-524
+    def _calculate_accessibility_score(self, m):
+        height, width = m.shape
+        y_grid, x_grid = np.ogrid[:height, :width]
+        dist = np.sqrt((x_grid - self.camera_cx) ** 2 + (y_grid - self.camera_cy) ** 2)
+        max_dist = np.sqrt(width ** 2 + height ** 2)
+        amap = 1 - (dist / max_dist)
+        angle = np.arctan2(y_grid - self.camera_cy, x_grid - self.camera_cx)
+        return (0.7 * amap + 0.3 * np.cos(angle)) * m
+
+    # :569-593  (depth argument is unused by the reference)
+    def calculate_approach_vector_score(self, m):
+        height, width = m.shape
+        y, x = np.indices((height, width))
+        vx = x - self.camera_cx
+        vy = y - self.camera_cy
+        norms = np.sqrt(vx * vx + vy * vy + float(self.f_norm) ** 2)
+        norms[norms == 0] = 1
+        return np.abs(self.f_norm / norms) * m
+
+    # :718-752
+    def estimate_leaf_orientation(self, m):
+        r = leaf_orientation_raw(m)
+        if r is None:
+            return None, None, None, None
+        return r[0], r[1], r[2], (r[3], r[4])
+
+    # :526-567
+    def calculate_sdf_score(self, m, return_parts=False):
+        m = np.ascontiguousarray(m, np.uint8)
+        dist_inside = distance_transform(m, 5)
+        dist_outside = distance_transform(1 - m, 5)
+        sdf = dist_inside - dist_outside
+        optimal_distance = 20
+        interior = np.exp(-((dist_inside - optimal_distance) ** 2) / (2 * optimal_distance ** 2))
+        sdf = sdf / np.max(np.abs(sdf))
+        y, x = np.indices(m.shape)
+        vx = (x - self.camera_cx).astype(np.float64)
+        vy = (y - self.camera_cy).astype(np.float64)
+        norms = np.sqrt(vx * vx + vy * vy)
+        norms[norms == 0] = 1
+        vx = vx / norms
+        vy = vy / norms
+        angle, _, _, _ = self.estimate_leaf_orientation(m)
+        if angle is not None:
+            # np.abs(np.cross(v, (cos a, sin a))) for 2-vectors = |vx*sin a - vy*cos a|  (:556-558)
+            align = np.abs(vx * np.sin(angle) - vy * np.cos(angle))
+        else:
+            align = np.ones_like(sdf)
+        final = (0.4 * interior + 0.4 * align + 0.2 * sdf) * m
+        if return_parts:
+            return final, dict(dist_inside=dist_inside, dist_outside=dist_outside, angle=angle)
+        return final
+
+    # :595-633
+    def _calculate_isolation_score(self, m):
+        height, width = m.shape
+        kernel_close = ellipse_se(30)
+        kernel_wide = ellipse_se(40)
+        current = m.astype(np.uint8)
+        all_leaves = (m > 0).astype(np.uint8)
+        other = all_leaves - current
+        ic = dilate(other, kernel_close)
+        dc = distance_transform(1 - ic, 3)
+        sc = dc / (np.max(dc) + 1e-6)
+        iw = dilate(other, kernel_wide)
+        dw = distance_transform(1 - iw, 3)
+        sw = dw / (np.max(dw) + 1e-6)
+        iso = (0.7 * sc + 0.3 * sw).astype(np.float32)  # float32 array * python float stays float32
+        yc = np.linspace(1.0, 0.2, height)[:, np.newaxis]
+        hp = np.tile(yc, (1, width))
+        return iso * hp * current
+
+    # :688-701
+    def _calculate_stem_penalty(self, m):
+        bottom = np.zeros_like(m)
+        h, w = m.shape
+        third = h // 3
+        bottom[-third:, :] = 1
+        masked_bottom = m & bottom
+        stem = dilate(masked_bottom, ellipse_se(30)) & m
+        return stem.astype(np.float32)
+
+    # :256-280
+    def _calculate_all_scores(self, m, depth_f32):
+        m = np.ascontiguousarray(m, np.uint8)
+        sdf, parts = self.calculate_sdf_score(m, return_parts=True)
+        scores = {
+            "sdf_score": sdf,
+            "approach_score": self.calculate_approach_vector_score(m),
+            "flatness_map": flatness_map(np.asarray(depth_f32, np.float32) * m.astype(np.float32),
+                                         self.gaussian_size),
+            "isolation_map": self._calculate_isolation_score(m),
+            "distance_map": distance_transform(m, 5),  # :266 (recomputed by the reference)
+            "accessibility_map": self._calculate_accessibility_score(m),
+            "stem_penalty": self._calculate_stem_penalty(m).astype(np.float32),
+        }
+        scores["traditional_score"] = (
+            0.4 * scores["approach_score"] + 0.3 * scores["sdf_score"]
+            + 0.2 * scores["flatness_map"] + 0.1 * scores["accessibility_map"]
+        ) * (1 - scores["stem_penalty"])
+        self._last_angle = parts["angle"]
+        return scores
+
+    # :282-288
+    def _get_valid_regions(self, m, scores):
+        return (scores["distance_map"] > self.min_edge_distance) & (m > 0) & (scores["stem_penalty"] < 0.8)
+
+    # :447-482.  tie_rule="total": score desc then flat index desc (the build's documented
+    # total order); tie_rule="numpy": the reference's np.argsort()[::-1].
+    def _get_candidate_points(self, score_map, valid, top_k=20, min_distance=10, tie_rule="total"):
+        vs = np.asarray(score_map * valid)
+        H, W = vs.shape
+        flat = vs.ravel() + 0.0  # -0.0 -> +0.0
+        if tie_rule == "numpy":
+            order = np.argsort(flat)[::-1]
+        else:
+            order = np.lexsort((-np.arange(flat.size), -flat))
+        order = np.ascontiguousarray(order, np.int64)
+        out = np.zeros((top_k, 2), np.int32)
+        n = _lib().lg_greedy_nms(order.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), order.size, H, W,
+                                 int(top_k), int(min_distance), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        return [(int(out[i, 0]), int(out[i, 1])) for i in range(n)]
+
+    # :392-445  (numpy branch; replicate padding at the image border)
+    @staticmethod
+    def _extract_local_patch(arr, x, y, size=32):
+        half = size // 2
+        h, w = arr.shape
+        x1, x2 = max(0, x - half), min(w, x + half)
+        y1, y2 = max(0, y - half), min(h, y + half)
+        patch = arr[y1:y2, x1:x2].copy()
+        pl, pr = half - (x - x1), half - (x2 - x)
+        pt, pb = half - (y - y1), half - (y2 - y)
+        if min(pl, pr, pt, pb) < 0:
+            return None
+        if pl + pr + pt + pb > 0:
+            patch = np.pad(patch, ((pt, pb), (pl, pr)), mode="edge")
+        return patch if patch.shape == (size, size) else None
+
+    # :59-143 feature assembly (9 channels, per-patch min-max when max>min; mask channel raw)
+    def patch_features(self, m, depth_f32, scores, point):
+        x, y = point
+        d = self._extract_local_patch(np.asarray(depth_f32, np.float32), x, y).astype(np.float32)
+        mk = self._extract_local_patch(np.asarray(m), x, y).astype(np.float32)
+        if d.max() > d.min():
+            d = (d - d.min()) / (d.max() - d.min())
+        chans = [d, mk]
+        for name in ("sdf_score", "approach_score", "flatness_map", "isolation_map", "distance_map",
+                     "accessibility_map", "stem_penalty"):
+            p = self._extract_local_patch(scores[name], x, y).astype(np.float32)
+            if p.max() > p.min():
+                p = (p - p.min()) / (p.max() - p.min())
+            chans.append(p)
+        return np.stack(chans).astype(np.float32)
+
+    @staticmethod
+    def ml_post(logit):
+        """:133-136  sigmoid -> tanh(3 s)/2 + 1/2"""
+        s = 1.0 / (1.0 + math.exp(-float(logit)))
+        return float(np.tanh(s * 3.0) * 0.5 + 0.5)
+
+    # :152-180 (pcl_data branch is never taken: :166-167)
+    def get_3d_grasp_point(self, pt, depth_f32):
+        u, v = pt
+        z = float(depth_f32[v, u])
+        return (z * (u - self.camera_cx) / self.f_norm, z * (v - self.camera_cy) / self.f_norm, z)
+
+    # :821-826
+    def _project_point_to_2d(self, p):
+        x, y, z = p
+        return (int((x * self.f_norm / z) + self.camera_cx), int((y * self.f_norm / z) + self.camera_cy))
+
+    # :754-819
+    def calculate_pre_grasp_point(self, g3, m):
+        g = np.array(g3, dtype=np.float64)
+        direction = g / np.linalg.norm(g)
+        dil = dilate(m, ellipse_se(31))
+        min_d, max_d, step = 0.05, 0.10, 0.01
+        for dist in np.arange(min_d, max_d, step):
+            t = (g3[0] - direction[0] * dist, g3[1] - direction[1] * dist, g3[2])
+            u, v = self._project_point_to_2d(t)
+            if not (0 <= u < m.shape[1] and 0 <= v < m.shape[0]):
+                continue
+            if dil[v, u] == 0:
+                if np.linalg.norm(np.array(t) - g) >= min_d:
+                    return t
+        return (g3[0] - direction[0] * max_d, g3[1] - direction[1] * max_d, g3[2])
+
+    # :184-253
+    def select_grasp_point(self, m, depth_f32, tie_rule="total", mask_is_bool=True, return_debug=False):
+        m = np.ascontiguousarray(m, np.uint8)
+        depth_f32 = np.asarray(depth_f32, np.float32)
+        scores = self._calculate_all_scores(m, depth_f32)
+        valid = self._get_valid_regions(m, scores)
+        cands = self._get_candidate_points(scores["traditional_score"], valid, 20, 10, tie_rule)
+        if not cands:
+            return (None, None, None) if not return_debug else ((None, None, None), {})
+        best = cands[0]
+        best_score = scores["traditional_score"][best[1], best[0]]
+        ml_scores = []
+        if self.cnn is not None and len(cands) > 1:
+            H, W = m.shape
+            for (x, y) in cands:
+                trad = scores["traditional_score"][y, x]
+                # Appendix B.7: with a torch *bool* mask the reference cannot replicate-pad a
+                # border-overlapping patch (F.pad has no bool kernel) -> ml score None -> skipped.
+                if mask_is_bool and (x < 16 or y < 16 or x + 16 > W or y + 16 > H):
+                    ml_scores.append(None)
+                    continue
+                feat = self.patch_features(m, depth_f32, scores, (x, y))
+                ml = self.ml_post(self.cnn(feat[None])[0])
+                ml_scores.append(ml)
+                conf = 1.0 - abs(ml - 0.5) * 2
+                w = min(0.3, conf * 0.6)
+                comb = (1.0 - w) * trad + w * ml
+                if comb > best_score:
+                    best_score = comb
+                    best = (x, y)
+        g3 = self.get_3d_grasp_point(best, depth_f32)
+        pre = self.calculate_pre_grasp_point(g3, m)
+        res = (best, g3, pre)
+        if return_debug:
+            return res, dict(scores=scores, valid=valid, candidates=cands, ml_scores=ml_scores)
+        return res
+
+
+# --------------------------------------------------------------------------- model.py
+CNN_FILTERS = (64, 128, 256)
+
+
+def cnn_param_shapes(in_channels=9, filters=CNN_FILTERS):
+    """state_dict layout of GraspPointCNN(in_channels=9) default config
+    (scripts/utils/ml_grasp_optimizer/model.py:16-84)."""
+    shapes = {}
+    c = in_channels
+    for b, f in enumerate(filters):
+        for conv, bn, cin in ((0, 1, c), (3, 4, f)):
+            shapes[f"encoder.{b}.{conv}.weight"] = (f, cin, 3, 3)
+            shapes[f"encoder.{b}.{conv}.bias"] = (f,)
+            for s in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"encoder.{b}.{bn}.{s}"] = (f,)
+        c = f
+    F = filters[-1]
+    shapes["attention.0.weight"] = (1, F, 1, 1)
+    shapes["attention.0.bias"] = (1,)
+    dims = [F, F, F // 2, F // 4, 1]
+    for li, idx in enumerate((0, 4, 8, 12)):
+        shapes[f"classifier.{idx}.weight"] = (dims[li + 1], dims[li])
+        shapes[f"classifier.{idx}.bias"] = (dims[li + 1],)
+        if idx != 12:
+            for s in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"classifier.{idx + 1}.{s}"] = (dims[li + 1],)
+    return shapes
+
+
+def _hash_unit(idx, salt):
+    """Integer hash -> [-1, 1): exactly reproducible on any host (no libm involved)."""
+    x = (idx.astype(np.uint64) * np.uint64(2654435761) + np.uint64(salt)) & np.uint64(0xFFFFFFFF)
+    for _ in range(2):
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x45D9F3B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.float64) / 4294967296.0 * 2.0 - 1.0
+
+
+def cnn_closed_form_params(seed=0, in_channels=9):
+    """Deterministic closed-form fill (no trained best_model.pth exists in the reference tree,
+    SURVEY 8d): integer-hash uniform weights with kaiming-uniform scale, non-trivial BN
+    gamma/beta/mean/var so BN folding is exercised.  Logits vary with the input (unlike a
+    smooth sin fill, which averages out under global pooling)."""
+    params = {}
+    for i, (name, shp) in enumerate(cnn_param_shapes(in_channels).items()):
+        n = int(np.prod(shp))
+        base = _hash_unit(np.arange(n), 7919 * (i + 1) + 104729 * seed)
+        if name.endswith("running_var"):
+            v = 0.8 + 0.4 * (0.5 + 0.5 * base)
+        elif name.endswith("running_mean"):
+            v = 0.05 * base
+        elif ".weight" in name and len(shp) == 1:  # BN gamma
+            v = 1.0 + 0.1 * base
+        elif name.endswith("bias"):
+            v = 0.05 * base
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            v = base * math.sqrt(6.0 / fan_in)
+        params[name] = v.reshape(shp).astype(np.float32)
+    return params
+
+
+def synthetic_patches(n=20, seed=5):
+    """Seeded [n,9,32,32] float32 CNN inputs: first half uniform noise, second half noise + blobs."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, 9, 32, 32)).astype(np.float32)
+    yy, xx = np.mgrid[0:32, 0:32]
+    for b in range(n // 2, n):
+        for c in range(9):
+            cx, cy = rng.uniform(0, 32, 2)
+            s = rng.uniform(3, 12)
+            x[b, c] = 0.5 * x[b, c] + (0.5 * rng.uniform(0.2, 1)
+                                       * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))).astype(np.float32)
+    return x
+
+
+def cnn_forward(params, x, dtype=None):
+    """GraspPointCNN.forward in eval mode (model.py:101-128), default 'spatial' attention.
+    torch (CPU) functional restatement; x [B,9,32,32] -> logits [B]."""
+    import torch
+    import torch.nn.functional as F
+
+    dt = dtype or torch.float32
+    p = {k: torch.as_tensor(v).to(dt) for k, v in params.items()}
+    h = torch.as_tensor(x).to(dt)
+    with torch.no_grad():
+        for b in range(3):
+            for conv, bn in ((0, 1), (3, 4)):
+                h = F.conv2d(h, p[f"encoder.{b}.{conv}.weight"], p[f"encoder.{b}.{conv}.bias"], padding=1)
+                h = F.batch_norm(h, p[f"encoder.{b}.{bn}.running_mean"], p[f"encoder.{b}.{bn}.running_var"],
+                                 p[f"encoder.{b}.{bn}.weight"], p[f"encoder.{b}.{bn}.bias"], False, 0.0, 1e-5)
+                h = F.relu(h)
+            h = F.max_pool2d(h, 2)
+        att = torch.sigmoid(F.conv2d(h, p["attention.0.weight"], p["attention.0.bias"]))
+        h = (h * att).mean(dim=(2, 3))
+        for idx in (0, 4, 8):
+            h = F.linear(h, p[f"classifier.{idx}.weight"], p[f"classifier.{idx}.bias"])
+            h = F.batch_norm(h, p[f"classifier.{idx + 1}.running_mean"], p[f"classifier.{idx + 1}.running_var"],
+                             p[f"classifier.{idx + 1}.weight"], p[f"classifier.{idx + 1}.bias"], False, 0.0, 1e-5)
+            h = F.relu(h)
+        h = F.linear(h, p["classifier.12.weight"], p["classifier.12.bias"])
+    return h.reshape(-1).to(torch.float64).numpy()
+
+
+# --------------------------------------------------------------------------- leaf_scorer.py
+def visibility_score(leaf_mask):
+    """OptimalLeafSelector._calculate_visibility_score (scripts/utils/leaf_scorer.py:277-306)."""
+    h, w = leaf_mask.shape
+    ys, xs = np.where(leaf_mask)
+    if len(ys) == 0:
+        return 0.0
+    border = np.sum(leaf_mask[0, :]) + np.sum(leaf_mask[-1, :]) + np.sum(leaf_mask[:, 0]) + np.sum(leaf_mask[:, -1])
+    if border > 0:
+        return 0.0
+    cx, cy = np.mean(xs), np.mean(ys)
+    d = np.sqrt((cx - w / 2) ** 2 + (cy - h / 2) ** 2)
+    return 1.0 - d / np.sqrt((w / 2) ** 2 + (h / 2) ** 2)
+
+
+def clutter_extrema(labels):
+    """leaf_scorer.py:66-71.  The reference runs skfmm.distance (scikit-fmm 2022.3.26, absent here)
+    on phi = 0 on any leaf / 1 elsewhere and only consumes argmin / argmax.  Build semantics
+    (DESIGN.md): exact Euclidean distance to the nearest leaf pixel; argmin = first leaf pixel,
+    argmax = first maximum in row-major order.  PARITY UNPINNED vs scikit-fmm."""
+    from scipy import ndimage
+
+    leaf = np.asarray(labels) >= 1
+    field = ndimage.distance_transform_edt(~leaf)
+    mn = np.unravel_index(field.argmin(), field.shape)
+    mx = np.unravel_index(field.argmax(), field.shape)
+    return mn, mx
+
+
+def pareto_max(scores):
+    """paretoset(scores, sense=['max']*3) (paretoset 1.2.3, absent here): non-dominated rows,
+    only the first of identical rows kept.  O(n^2) restatement.  PARITY UNPINNED."""
+    s = np.asarray(scores, np.float64)
+    n = len(s)
+    keep = np.ones(n, bool)
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                continue
+            if np.all(s[j] >= s[i]) and (np.any(s[j] > s[i]) or j < i):
+                keep[i] = False
+                break
+    return keep
+
+
+class RefOptimalLeafSelector:
+    """Restatement of scripts/utils/leaf_scorer.py::OptimalLeafSelector.select_optimal_leaf (:25-203)."""
+
+    def __init__(self):
+        self.camera_cx = self.camera_cy = self.f_norm = None
+        self._tall_leaves = []
+
+    def set_camera_params(self, P):  # :19-23
+        self.f_norm, self.camera_cx, self.camera_cy = P[0, 0], P[0, 2], P[1, 2]
+
+    def get_tall_leaves(self):  # :205-207
+        return self._tall_leaves
+
+    def select_optimal_leaf(self, labels_i16, depth_f32, return_debug=False):
+        mask_np = np.asarray(labels_i16)
+        depth_np = np.asarray(depth_f32, np.float32)
+        leaf_ids = np.unique(mask_np)[1:]  # torch.unique(mask)[1:]  (:32)
+        depth_list, leaf_masks = [], []
+        for lid in leaf_ids:
+            lm = mask_np == lid
+            leaf_masks.append(lm)
+            d = depth_np[lm]
+            if len(d) > 0:
+                depth_list.append(np.median(d))
+        if not depth_list:
+            return None
+        depth_mean = np.mean(np.array(depth_list))
+        tall = [int(leaf_ids[i]) for i, d in enumerate(depth_list) if d < depth_mean]
+        mn, mx = clutter_extrema(mask_np)
+        cands = []
+        for idx, lid in enumerate(leaf_ids):
+            lm = leaf_masks[idx]
+            if np.sum(lm) < 10000:
+                continue
+            ys, xs = np.where(lm)
+            c = (np.mean(xs), np.mean(ys))
+            dmin = np.sqrt((c[0] - mn[1]) ** 2 + (c[1] - mn[0]) ** 2)
+            dmax = np.sqrt((c[0] - mx[1]) ** 2 + (c[1] - mx[0]) ** 2)
+            tot = dmin + dmax
+            clutter = dmin / tot if tot > 0 else 0
+            mean_depth = np.mean(depth_np[lm])
+            X = (mean_depth * (xs - self.camera_cx)) / self.f_norm
+            Y = (mean_depth * (ys - self.camera_cy)) / self.f_norm
+            Z = np.full_like(X, mean_depth)
+            mean_distance = np.mean(np.sqrt(X ** 2 + Y ** 2 + Z ** 2))
+            dist_score = np.exp(-mean_distance / 0.3)
+            vis = visibility_score(lm)
+            cands.append(dict(leaf_id=int(lid), scores=np.array([clutter, dist_score, vis], np.float64),
+                              mean_distance=float(mean_distance), is_tall=int(lid) in tall))
+        if not cands:
+            return None
+        tall_c = [c for c in cands if c["is_tall"]]
+        reg_c = [c for c in cands if not c["is_tall"]]
+        if tall_c:
+            sc = np.stack([c["scores"] for c in tall_c]) * 1.1
+            pm = pareto_max(sc)
+            pc = [c for i, c in enumerate(tall_c) if pm[i]]
+        else:
+            sc = np.stack([c["scores"] for c in reg_c])
+            pm = pareto_max(sc)
+            pc = [c for i, c in enumerate(reg_c) if pm[i]]
+        if not pc:
+            pc = tall_c if tall_c else reg_c
+        w = np.array([0.35, 0.35, 0.3])
+        best, best_s = None, float("-inf")
+        self._tall_leaves = tall
+        for c in pc:
+            s = np.sum(w * c["scores"])
+            if s > best_s:
+                best_s, best = s, c["leaf_id"]
+        if return_debug:
+            return best, dict(candidates=cands, tall=tall, extrema=(mn, mx), depth_list=depth_list)
+        return best
+
+
+# --------------------------------------------------------------------------- synthetic scenes
+def synthetic_scene(H, W, seed=0):
+    """Seeded synthetic frame per SURVEY.md 8(d): int16 label image of filled rotated ellipses,
+    planar+noise float32 depth, 3x4 projection matrix.  Leaf 1 is kept fully interior with area
+    >= 10000 px at >=720p sizes; one leaf touches the border."""
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(4, 11))
+    labels = np.zeros((H, W), np.int16)
+    depth = np.full((H, W), 0.70, np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k in range(1, L + 1):
+        a = rng.uniform(0.06, 0.14) * W
+        b = rng.uniform(0.03, 0.08) * W
+        ang = np.deg2rad(rng.uniform(0, 180))
+        if k == 1:  # interior leaf, big enough
+            a = max(a, 0.10 * W)
+            b = max(b, 0.06 * W)
+            r = math.hypot(a, b)
+            cx = rng.uniform(min(r + 2, W / 2), max(W - r - 2, W / 2))
+            cy = rng.uniform(min(r + 2, H / 2), max(H - r - 2, H / 2))
+        elif k == 2:  # border toucher
+            cx, cy = rng.uniform(0, W), rng.choice([0.0, H - 1.0])
+        else:
+            cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        ca, sa = math.cos(ang), math.sin(ang)
+        u = (xx - cx) * ca + (yy - cy) * sa
+        v = -(xx - cx) * sa + (yy - cy) * ca
+        inside = (u / a) ** 2 + (v / b) ** 2 <= 1.0
+        if k > 1:
+            inside &= labels != 1  # keep leaf 1 un-occluded so it stays a valid candidate
+        labels[inside] = k
+        zk = rng.uniform(0.35, 0.60)
+        ak, bk = rng.uniform(-2e-4, 2e-4, size=2)
+        plane = zk + ak * (xx - cx) + bk * (yy - cy)
+        depth[inside] = plane[inside].astype(np.float32)
+    depth = (depth + rng.normal(0, 0.002, size=(H, W))).astype(np.float32)
+    P = np.array([[1750.68 * (W / 1440), 0, 707.87 * (W / 1440), -200.0],
+                  [0, 1749.7 * (H / 1080), 494.07 * (H / 1080), 0],
+                  [0, 0, 1, 0]], np.float64)
+    return labels, depth, P
