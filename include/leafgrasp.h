@@ -1,0 +1,181 @@
+/*
+ * leafgrasp.h -- C-ABI of the MI355X (gfx950) grasp-scoring library, liblgrasp.so.
+ *
+ * Drop-in boundary for the per-pixel grasp-scoring hot path of
+ * Srecharan/Leaf-Grasping-Vision-ML (reference paths are relative to the reference repo root).
+ * Plain pointers and sizes only; no torch types.  All image pointers are DEVICE pointers owned by
+ * the caller (e.g. torch tensor.data_ptr()); frames are dense row-major [B][H][W].
+ * Every entry point returns 0 (LG_OK) or a negative lg_status; nothing throws, nothing exits.
+ * One handle <-> one device; calls on one handle are stream-ordered; handles are independent and
+ * the library keeps no global mutable state (SURVEY.md 8b "Threading").
+ *
+ * Reference interfaces replaced (what a ctypes/cffi binding in the reference would call):
+ *   lg_score_maps      GraspPointSelector._calculate_all_scores + _get_valid_regions
+ *                      (scripts/utils/grasp_point_selector.py:256-288) and everything they call:
+ *                      calculate_sdf_score :526-567, calculate_approach_vector_score :569-593,
+ *                      _calculate_flatness_map :635-657 + ImageProcessor.smooth_depth
+ *                      (scripts/utils/image_processor.py:56-64), _calculate_isolation_score :595-633,
+ *                      cv2.distanceTransform :266, _calculate_accessibility_score :502-524,
+ *                      _calculate_stem_penalty :688-701, estimate_leaf_orientation :718-752
+ *   lg_topk_nms        GraspPointSelector._get_candidate_points  :447-482
+ *   lg_gather_patches  get_ml_score feature assembly :59-127 + _extract_local_patch :392-445
+ *   lg_cnn_load / lg_cnn_forward   GraspPointCNN.forward (eval)
+ *                      (scripts/utils/ml_grasp_optimizer/model.py:101-128), load_ml_model :43-57
+ *   lg_select_grasp    GraspPointSelector.select_grasp_point :184-253 (whole path, batched)
+ *   lg_leaf_stats      the per-leaf passes of OptimalLeafSelector.select_optimal_leaf
+ *                      (scripts/utils/leaf_scorer.py:32-47,66-71,74-138)
+ */
+#ifndef LEAFGRASP_H
+#define LEAFGRASP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lg_ctx* lg_handle;
+
+typedef enum lg_status {
+    LG_OK = 0,
+    LG_ERR_INVALID = -1,  /* bad argument (null pointer, non-positive size, unsupported shape) */
+    LG_ERR_HIP = -2,      /* a HIP runtime call failed; see lg_last_error */
+    LG_ERR_NOMEM = -3,
+    LG_ERR_NO_MODEL = -4, /* lg_cnn_forward without lg_cnn_load (reference: ml_predictor is None) */
+    LG_ERR_UNSUPPORTED = -5
+} lg_status;
+
+/* Indices into out_maps[] -- the keys of the reference's `scores` dict
+   (grasp_point_selector.py:258-280), in get_ml_score's channel order (:95-99) + traditional. */
+enum {
+    LG_MAP_SDF = 0,        /* 'sdf_score' */
+    LG_MAP_APPROACH = 1,   /* 'approach_score' */
+    LG_MAP_FLATNESS = 2,   /* 'flatness_map' */
+    LG_MAP_ISOLATION = 3,  /* 'isolation_map' */
+    LG_MAP_DISTANCE = 4,   /* 'distance_map' */
+    LG_MAP_ACCESS = 5,     /* 'accessibility_map' */
+    LG_MAP_STEM = 6,       /* 'stem_penalty' */
+    LG_MAP_TRADITIONAL = 7,/* 'traditional_score' */
+    LG_NUM_MAPS = 8
+};
+
+/* Every constant of the path; lg_default_params fills the reference values. */
+typedef struct lg_params {
+    float cx, cy, f;                 /* camera: P[0,2], P[1,2], P[0,0]  (:145-150); defaults 707, 494, 0 (unset) */
+    float w_approach, w_sdf, w_flat, w_access;      /* 0.4 0.3 0.2 0.1            (:272-277) */
+    float sdf_w_interior, sdf_w_align, sdf_w_sdf;   /* 0.4 0.4 0.2                (:563-565) */
+    float optimal_distance;                         /* 20 px                      (:535-536) */
+    float access_w_dist, access_w_dir;              /* 0.7 0.3                    (:522)     */
+    float flat_scale;                               /* 5                          (:655)     */
+    float iso_w_close, iso_w_wide;                  /* 0.7 0.3                    (:620)     */
+    float iso_ramp_top, iso_ramp_bottom;            /* 1.0 0.2                    (:623)     */
+    float min_edge_distance;                        /* 20                         (:25,285)  */
+    float stem_valid_thresh;                        /* 0.8                        (:287)     */
+    int32_t stem_se;                                /* ellipse 30                 (:696)     */
+    int32_t stem_bottom_div;                        /* bottom H//3 rows           (:693)     */
+    int32_t top_k;                                  /* 20                         (:197)     */
+    int32_t nms_min_distance;                       /* 10                         (:198)     */
+    int32_t pregrasp_clearance;                     /* 15 px (SE 31)              (:777-778) */
+    int32_t mask_is_bool;                           /* 1: torch.bool mask => border patches give no ML score */
+} lg_params;
+
+/* Raw GraspPointCNN(in_channels=9, 'spatial', [64,128,256]) state_dict tensors, HOST pointers,
+   float32, PyTorch layouts (conv: [Cout][Cin][3][3], linear: [out][in]); BN is folded at load. */
+typedef struct lg_cnn_weights {
+    const float* conv_w[6];  const float* conv_b[6];       /* encoder.{0,1,2}.{0,3} */
+    const float* bn_g[6]; const float* bn_b[6]; const float* bn_m[6]; const float* bn_v[6]; /* encoder.{b}.{1,4} */
+    const float* att_w; const float* att_b;               /* attention.0 : [1][256][1][1], [1] */
+    const float* fc_w[4]; const float* fc_b[4];            /* classifier.{0,4,8,12} */
+    const float* fbn_g[3]; const float* fbn_b[3]; const float* fbn_m[3]; const float* fbn_v[3]; /* classifier.{1,5,9} */
+    float bn_eps;                                          /* 1e-5 */
+} lg_cnn_weights;
+
+/* Per-frame result of lg_select_grasp (HOST memory). */
+typedef struct lg_grasp_result {
+    int32_t found;            /* 0 => reference returns (None, None, None) */
+    int32_t x, y;             /* grasp_point_2d */
+    float   X, Y, Z;          /* grasp_point_3d   (:152-180) */
+    int32_t has_pre;          /* pre-grasp point present */
+    float   pX, pY, pZ;       /* pre_grasp_point  (:754-819) */
+    int32_t n_candidates;
+    int32_t ml_used;          /* a CNN-rescored candidate replaced the best traditional one */
+    float   best_score;
+    float   theta;            /* leaf orientation (rad), NaN if none */
+} lg_grasp_result;
+
+/* Per-leaf statistics of lg_leaf_stats (HOST memory), one per label id present, ascending id. */
+typedef struct lg_leaf_stat {
+    int32_t id;
+    int32_t area;             /* pixel count                          (leaf_scorer.py:79) */
+    int32_t touches_border;   /* any pixel on the image border        (:286-291) */
+    int32_t pad_;
+    double  sum_x, sum_y;     /* centroid numerators                  (:84-88)   */
+    double  sum_depth;        /* mean depth numerator                 (:105-106) */
+    double  sum_ray;          /* sum over pixels of sqrt((x-cx)^2+(y-cy)^2+f^2)  (:109-115) */
+    float   median_depth;     /* np.median of the leaf's depths       (:41-47)   */
+    float   pad2_;
+} lg_leaf_stat;
+
+int lg_create(int device, lg_handle* out);
+int lg_destroy(lg_handle h);
+const char* lg_last_error(lg_handle h);
+const char* lg_version(void);
+void lg_default_params(lg_params* p);
+
+/* Score planes for B frames.  depth [B][H][W] f32, mask [B][H][W] u8 (0/1), out_maps[i] [B][H][W] f32
+   (any entry may be NULL = not wanted, except DISTANCE/TRADITIONAL which later stages need),
+   out_valid [B][H][W] u8 (may be NULL).  theta_host (optional, HOST, B floats) receives the leaf
+   axis angle per frame (NaN when the mask has no contour).  Work is enqueued on `stream`
+   (a hipStream_t, NULL = default stream); the call synchronises internally only with its own
+   copy stream (orientation hand-off), not with `stream`. */
+int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W,
+                  const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
+                  float* theta_host, void* stream);
+
+/* Greedy spaced top-k on valid_scores = trad*valid (score desc, flat index desc on ties).
+   out_xy [B][k][2] int32 (x,y) DEVICE, out_n [B] int32 DEVICE. */
+int lg_topk_nms(lg_handle h, const float* trad, const uint8_t* valid, int B, int H, int W, int k,
+                int min_dist, int32_t* out_xy, int32_t* out_n, void* stream);
+
+/* 9-channel 32x32 patches around n_xy points per frame.  maps[] as produced by lg_score_maps
+   (indices 0..6 are read).  xy [B][k][2] DEVICE, n [B] DEVICE; patches [B][k][9][32][32] f32 DEVICE. */
+int lg_gather_patches(lg_handle h, const float* depth, const uint8_t* mask,
+                      const float* const maps[LG_NUM_MAPS], int B, int H, int W, int k,
+                      const int32_t* xy, const int32_t* n, float* patches, void* stream);
+
+int lg_cnn_load(lg_handle h, const lg_cnn_weights* w);
+int lg_cnn_unload(lg_handle h);
+/* patches [N][9][32][32] f32 DEVICE -> logits [N] f32 DEVICE. */
+int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void* stream);
+
+/* Whole GraspPointSelector.select_grasp_point for B frames: maps -> valid -> top-k -> (CNN rescoring
+   if a model is loaded) -> 3-D point -> pre-grasp.  out_maps / out_valid may be NULL (library
+   workspace is used).  results: HOST array of B.  Synchronises `stream` before returning. */
+int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W,
+                    const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
+                    lg_grasp_result* results, void* stream);
+
+/* Per-label statistics + clutter extrema for one frame.  labels [H][W] int16 DEVICE, depth DEVICE.
+   stats: HOST array of capacity max_leaves; n_leaves: HOST.  extrema (HOST, 4 ints): first leaf
+   pixel (y,x) and the background pixel farthest (exact Euclidean) from any leaf (y,x). */
+int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H, int W,
+                  float cx, float cy, float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves,
+                  int32_t* extrema, void* stream);
+
+/* GraspPointSelector.estimate_leaf_orientation (:718-752) for one frame: mask [H][W] u8 DEVICE.
+   out (HOST, 5 floats): angle (rad, direction of the longer side of the min-area rectangle of the largest
+   outer contour, in (0, pi]), major axis, minor axis, centre x, centre y.  Returns LG_OK and *found = 0
+   when the mask is empty.  Synchronises `stream`. */
+int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream);
+
+/* Per-kernel device timing with HIP events recorded on the launch stream (bench.py roofline).
+   lg_profile_enable(h,1) starts collecting; lg_profile_read returns, for kernel `name`
+   ("final", "dt_fwd", "dt_bwd", "prep", "stem", "topk", "gather", "cnn", ...), the number of
+   launches and their summed duration in milliseconds since the last enable. */
+int lg_profile_enable(lg_handle h, int on);
+int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEAFGRASP_H */

@@ -1,0 +1,567 @@
+// C-ABI of liblgrasp.so (see include/leafgrasp.h).  Host orchestration only: workspaces, streams,
+// the orientation hand-off, per-kernel event timing.  No exceptions cross the boundary.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lg_cnn.h"
+#include "lg_internal.h"
+
+#define LG_VERSION_STR "leafgrasp-gfx950 0.1"
+
+struct LgProfSlot {
+    std::string name;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+    int launches = 0;
+    double total_ms = 0.0;
+};
+
+struct lg_ctx {
+    int device = 0;
+    std::string err;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_copy = nullptr;
+    // workspace, sized for (capB, capH, capW)
+    int capB = 0, capH = 0, capW = 0, capK = 0;
+    uint32_t* tmp = nullptr;
+    unsigned long long *bits = nullptr, *stem = nullptr, *tilekeys = nullptr;
+    uint32_t* maxfix = nullptr;
+    LgFrameParams* fp_dev = nullptr;
+    LgFrameParams* fp_host = nullptr;        // pinned
+    unsigned long long* bits_host = nullptr;  // pinned
+    float* ws_maps[LG_NUM_MAPS] = {nullptr};
+    uint8_t* ws_valid = nullptr;
+    int32_t *cand_xy = nullptr, *cand_n = nullptr;
+    float *cand_info = nullptr, *patches = nullptr, *logits = nullptr;
+    int32_t *h_xy = nullptr, *h_n = nullptr;  // pinned
+    float *h_info = nullptr, *h_logits = nullptr;
+    LgCnn cnn;
+    bool prof_on = false;
+    std::vector<LgProfSlot> prof;
+    int host_threads = 8;
+};
+
+namespace {
+
+int fail(lg_handle h, int code, const char* what, hipError_t e = hipSuccess) {
+    if (h) {
+        char buf[512];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof(buf), "%s", what);
+        h->err = buf;
+    }
+    return code;
+}
+
+#define LG_HIP(h, call)                                                    \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) return fail(h, LG_ERR_HIP, #call, e_);       \
+    } while (0)
+
+struct ProfScope {  // records an event pair around a launch when profiling is on
+    lg_ctx* h;
+    hipStream_t s;
+    LgProfSlot* slot = nullptr;
+    hipEvent_t e1 = nullptr;
+    ProfScope(lg_ctx* h_, const char* name, hipStream_t s_) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        for (auto& p : h->prof)
+            if (p.name == name) slot = &p;
+        if (!slot) {
+            h->prof.push_back(LgProfSlot());
+            slot = &h->prof.back();
+            slot->name = name;
+        }
+        if (slot->used + 2 > slot->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { slot = nullptr; return; }
+            slot->ev.push_back(a);
+            slot->ev.push_back(b);
+        }
+        hipEventRecord(slot->ev[slot->used], s);
+        e1 = slot->ev[slot->used + 1];
+        slot->used += 2;
+    }
+    ~ProfScope() {
+        if (slot && e1) hipEventRecord(e1, s);
+    }
+};
+
+void prof_flush(lg_ctx* h) {  // resolve recorded pairs into totals (call after a synchronise)
+    for (auto& p : h->prof) {
+        for (size_t i = 0; i + 1 < p.used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
+                p.total_ms += ms;
+                p.launches++;
+            }
+        }
+        p.used = 0;
+    }
+}
+
+template <typename T>
+hipError_t dev_alloc(T** p, size_t n) {
+    return hipMalloc((void**)p, n * sizeof(T));
+}
+
+void free_ws(lg_ctx* h) {
+    auto F = [](void* p) { if (p) hipFree(p); };
+    F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->fp_dev);
+    for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps[i]); h->ws_maps[i] = nullptr; }
+    F(h->ws_valid); F(h->cand_xy); F(h->cand_n); F(h->cand_info); F(h->patches); F(h->logits);
+    auto HF = [](void* p) { if (p) hipHostFree(p); };
+    HF(h->fp_host); HF(h->bits_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
+    h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->fp_dev = nullptr;
+    h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
+    h->fp_host = nullptr; h->bits_host = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
+    h->capB = h->capH = h->capW = h->capK = 0;
+}
+
+int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
+    if (B <= h->capB && H == h->capH && W == h->capW && K <= h->capK) return LG_OK;
+    int nB = std::max(B, h->capB), nK = std::max(K, std::max(h->capK, 20));
+    hipDeviceSynchronize();
+    free_ws(h);
+    const size_t px = (size_t)nB * H * W;
+    const int WW = (W + 63) / 64;
+    const size_t words = (size_t)nB * H * WW;
+    const int tiles = ((W + LG_TW - 1) / LG_TW) * ((H + LG_TH - 1) / LG_TH);
+    LG_HIP(h, dev_alloc(&h->tmp, px * 2));
+    LG_HIP(h, dev_alloc(&h->bits, words));
+    LG_HIP(h, dev_alloc(&h->stem, words));
+    LG_HIP(h, dev_alloc(&h->tilekeys, (size_t)nB * tiles));
+    LG_HIP(h, dev_alloc(&h->maxfix, (size_t)nB * 2));
+    LG_HIP(h, dev_alloc(&h->fp_dev, (size_t)nB));
+    LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
+    LG_HIP(h, hipHostMalloc((void**)&h->bits_host, sizeof(unsigned long long) * words));
+    LG_HIP(h, dev_alloc(&h->cand_xy, (size_t)nB * nK * 2));
+    LG_HIP(h, dev_alloc(&h->cand_n, (size_t)nB));
+    LG_HIP(h, dev_alloc(&h->cand_info, (size_t)nB * nK * 2));
+    LG_HIP(h, dev_alloc(&h->patches, (size_t)nB * nK * 9 * 1024));
+    LG_HIP(h, dev_alloc(&h->logits, (size_t)nB * nK));
+    LG_HIP(h, hipHostMalloc((void**)&h->h_xy, sizeof(int32_t) * nB * nK * 2));
+    LG_HIP(h, hipHostMalloc((void**)&h->h_n, sizeof(int32_t) * nB));
+    LG_HIP(h, hipHostMalloc((void**)&h->h_info, sizeof(float) * nB * nK * 2));
+    LG_HIP(h, hipHostMalloc((void**)&h->h_logits, sizeof(float) * nB * nK));
+    h->capB = nB; h->capH = H; h->capW = W; h->capK = nK;
+    return LG_OK;
+}
+
+int ensure_ws_map(lg_ctx* h, int i) {  // internal plane when the caller does not want map i
+    if (h->ws_maps[i]) return LG_OK;
+    LG_HIP(h, dev_alloc(&h->ws_maps[i], (size_t)h->capB * h->capH * h->capW));
+    return LG_OK;
+}
+
+void gaussian1d(float k1[5]) {  // ImageProcessor._create_gaussian_kernel, size 5, sigma = 5/6 (image_processor.py:25-32)
+    const double sigma = 5.0 / 6.0;
+    double e[5], s = 0;
+    for (int i = 0; i < 5; i++) { e[i] = exp(-((i - 2) * (i - 2)) / (2 * sigma * sigma)); s += e[i]; }
+    for (int i = 0; i < 5; i++) k1[i] = (float)(e[i] / s);
+}
+
+void parallel_for(int n, int nthreads, const std::function<void(int)>& fn) {
+    if (n <= 1 || nthreads <= 1) {
+        for (int i = 0; i < n; i++) fn(i);
+        return;
+    }
+    int T = std::min(n, nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([=, &fn]() { for (int i = t; i < n; i += T) fn(i); });
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lg_version(void) { return LG_VERSION_STR; }
+
+void lg_default_params(lg_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->cx = 707.f; p->cy = 494.f; p->f = 0.f;  // grasp_point_selector.py:29-31 (f_norm unset)
+    p->w_approach = 0.4f; p->w_sdf = 0.3f; p->w_flat = 0.2f; p->w_access = 0.1f;
+    p->sdf_w_interior = 0.4f; p->sdf_w_align = 0.4f; p->sdf_w_sdf = 0.2f;
+    p->optimal_distance = 20.f;
+    p->access_w_dist = 0.7f; p->access_w_dir = 0.3f;
+    p->flat_scale = 5.f;
+    p->iso_w_close = 0.7f; p->iso_w_wide = 0.3f;
+    p->iso_ramp_top = 1.0f; p->iso_ramp_bottom = 0.2f;
+    p->min_edge_distance = 20.f; p->stem_valid_thresh = 0.8f;
+    p->stem_se = 30; p->stem_bottom_div = 3;
+    p->top_k = 20; p->nms_min_distance = 10;
+    p->pregrasp_clearance = 15;
+    p->mask_is_bool = 1;
+}
+
+int lg_create(int device, lg_handle* out) {
+    if (!out) return LG_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return LG_ERR_HIP;
+    lg_ctx* h = new (std::nothrow) lg_ctx();
+    if (!h) return LG_ERR_NOMEM;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return LG_ERR_HIP;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    h->host_threads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+    *out = h;
+    return LG_OK;
+}
+
+int lg_destroy(lg_handle h) {
+    if (!h) return LG_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    free_ws(h);
+    lg_cnn_free(&h->cnn);
+    for (auto& p : h->prof)
+        for (auto e : p.ev) hipEventDestroy(e);
+    if (h->ev_prep) hipEventDestroy(h->ev_prep);
+    if (h->ev_copy) hipEventDestroy(h->ev_copy);
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    delete h;
+    return LG_OK;
+}
+
+const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int lg_profile_enable(lg_handle h, int on) {
+    if (!h) return LG_ERR_INVALID;
+    for (auto& p : h->prof) { p.used = 0; p.launches = 0; p.total_ms = 0.0; }
+    h->prof_on = on != 0;
+    return LG_OK;
+}
+
+int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_ms) {
+    if (!h || !name) return LG_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    prof_flush(h);
+    if (launches) *launches = 0;
+    if (total_ms) *total_ms = 0.0;
+    for (auto& p : h->prof)
+        if (p.name == name) {
+            if (launches) *launches = p.launches;
+            if (total_ms) *total_ms = p.total_ms;
+            return LG_OK;
+        }
+    return LG_OK;
+}
+
+int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
+                  float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, float* theta_host, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!depth || !mask || B <= 0 || H < 8 || W < 8 || W > 8192 || H > 16384)
+        return fail(h, LG_ERR_INVALID, "lg_score_maps: bad pointer or shape (need H,W >= 8, W <= 8192)");
+    lg_params P;
+    if (pin) P = *pin; else lg_default_params(&P);
+    if (P.stem_se < 1 || P.stem_se > 64 || P.stem_bottom_div < 1)
+        return fail(h, LG_ERR_INVALID, "lg_score_maps: stem_se must be in [1,64], stem_bottom_div >= 1");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, B, H, W, P.top_k);
+    if (rc) return rc;
+    const int WW = (W + 63) / 64;
+    const int tiles_x = (W + LG_TW - 1) / LG_TW, tiles_y = (H + LG_TH - 1) / LG_TH;
+    if (tiles_x * tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "lg_score_maps: image too large for the top-k tile table");
+
+    float* maps[LG_NUM_MAPS];
+    for (int i = 0; i < LG_NUM_MAPS; i++) maps[i] = out_maps ? out_maps[i] : nullptr;
+    for (int i : {LG_MAP_DISTANCE, LG_MAP_TRADITIONAL})
+        if (!maps[i]) {
+            rc = ensure_ws_map(h, i);
+            if (rc) return rc;
+            maps[i] = h->ws_maps[i];
+        }
+
+    LG_HIP(h, hipMemsetAsync(h->maxfix, 0, sizeof(uint32_t) * 2 * B, s));
+    {
+        ProfScope ps(h, "prep", s);
+        lg_launch_pack_bits(mask, h->bits, B, H, W, WW, s);
+    }
+    LG_HIP(h, hipEventRecord(h->ev_prep, s));
+    LG_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_prep, 0));
+    LG_HIP(h, hipMemcpyAsync(h->bits_host, h->bits, sizeof(unsigned long long) * (size_t)B * H * WW, hipMemcpyDeviceToHost,
+                             h->copy_stream));
+    LG_HIP(h, hipEventRecord(h->ev_copy, h->copy_stream));
+    {
+        LgSeSpans se;
+        lg_make_se_spans(P.stem_se, &se);
+        ProfScope ps(h, "stem", s);
+        lg_launch_stem_bits(h->bits, h->stem, B, H, W, WW, H - H / P.stem_bottom_div, se, s);
+    }
+    {
+        ProfScope ps(h, "dt_fwd", s);
+        if (lg_launch_dt(false, mask, h->tmp, nullptr, h->maxfix, B, H, W, s)) return fail(h, LG_ERR_UNSUPPORTED, "dt: width");
+    }
+    {
+        ProfScope ps(h, "dt_bwd", s);
+        lg_launch_dt(true, mask, h->tmp, maps[LG_MAP_DISTANCE], h->maxfix, B, H, W, s);
+    }
+    // ---- orientation hand-off: host contour analysis overlaps the distance-transform sweeps
+    LG_HIP(h, hipEventSynchronize(h->ev_copy));
+    {
+        const unsigned long long* hb = h->bits_host;
+        LgFrameParams* fph = h->fp_host;
+        parallel_for(B, h->host_threads, [=](int b) {
+            double o[5];
+            int ok = lg_host_orientation(hb + (size_t)b * H * WW, H, W, WW, o);
+            LgFrameParams f;
+            f.has_angle = ok;
+            f.theta = ok ? (float)o[0] : NAN;
+            f.sin_t = ok ? (float)sin(o[0]) : 0.f;
+            f.cos_t = ok ? (float)cos(o[0]) : 0.f;
+            fph[b] = f;
+        });
+        if (theta_host)
+            for (int b = 0; b < B; b++) theta_host[b] = fph[b].theta;
+    }
+    LG_HIP(h, hipMemcpyAsync(h->fp_dev, h->fp_host, sizeof(LgFrameParams) * B, hipMemcpyHostToDevice, s));
+
+    LgFinalArgs a;
+    memset(&a, 0, sizeof(a));
+    a.depth = depth; a.bits = h->bits; a.stem_bits = h->stem; a.maxfix = h->maxfix; a.fp = h->fp_dev;
+    for (int i = 0; i < LG_NUM_MAPS; i++) a.maps[i] = maps[i];
+    a.valid = out_valid ? out_valid : h->ws_valid;
+    a.tilekeys = h->tilekeys;
+    a.B = B; a.H = H; a.W = W; a.WW = WW; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+    a.cx = P.cx; a.cy = P.cy; a.f = P.f;
+    a.w_approach = P.w_approach; a.w_sdf = P.w_sdf; a.w_flat = P.w_flat; a.w_access = P.w_access;
+    a.sdf_w_interior = P.sdf_w_interior; a.sdf_w_align = P.sdf_w_align; a.sdf_w_sdf = P.sdf_w_sdf;
+    a.optimal_distance = P.optimal_distance;
+    a.access_w_dist = P.access_w_dist; a.access_w_dir = P.access_w_dir; a.flat_scale = P.flat_scale;
+    a.iso_w_close = P.iso_w_close; a.iso_w_wide = P.iso_w_wide;
+    a.iso_ramp_top = P.iso_ramp_top; a.iso_ramp_bottom = P.iso_ramp_bottom;
+    {
+        // max of the chamfer-3 transform of an all-ones image: INIT + ceil(min(H,W)/2) * 0.955
+        uint32_t dmax = (uint32_t)((std::min(H, W) + 1) / 2);
+        float mx = (float)(LG_INIT0 + dmax * LG_A3) * (1.0f / 65536.0f);
+        a.iso_inv_max = 1.0f / mx;  // reference divides by (max + 1e-6), which rounds to max in float32
+    }
+    a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
+    a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
+    gaussian1d(a.k1);
+    {
+        ProfScope ps(h, "final", s);
+        lg_launch_final(a, s);
+    }
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_topk_nms(lg_handle h, const float* trad, const uint8_t* valid, int B, int H, int W, int k, int min_dist,
+                int32_t* out_xy, int32_t* out_n, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!trad || !valid || !out_xy || !out_n || B <= 0 || H < 1 || W < 1 || k < 1 || k > 64 || min_dist < 0)
+        return fail(h, LG_ERR_INVALID, "lg_topk_nms: bad argument (1 <= k <= 64)");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    const int tiles = ((W + LG_TW - 1) / LG_TW) * ((H + LG_TH - 1) / LG_TH);
+    if (tiles > 8192) return fail(h, LG_ERR_UNSUPPORTED, "lg_topk_nms: image too large");
+    int rc = ensure_ws(h, B, H, W, k);
+    if (rc) return rc;
+    ProfScope ps(h, "topk", s);
+    lg_launch_topk(trad, valid, nullptr, h->tilekeys, false, B, H, W, k, min_dist, out_xy, out_n, nullptr, s);
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_gather_patches(lg_handle h, const float* depth, const uint8_t* mask, const float* const maps[LG_NUM_MAPS], int B,
+                      int H, int W, int k, const int32_t* xy, const int32_t* n, float* patches, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!depth || !mask || !maps || !xy || !n || !patches || B <= 0 || k < 1)
+        return fail(h, LG_ERR_INVALID, "lg_gather_patches: bad argument");
+    for (int i = 0; i < 7; i++)
+        if (!maps[i]) return fail(h, LG_ERR_INVALID, "lg_gather_patches: maps[0..6] are required");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    ProfScope ps(h, "gather", s);
+    lg_launch_gather(depth, mask, maps, B, H, W, k, xy, n, patches, s);
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!mask || !out || !found || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_leaf_orientation: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 1, H, W, 20);
+    if (rc) return rc;
+    const int WW = (W + 63) / 64;
+    lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
+    LG_HIP(h, hipMemcpyAsync(h->bits_host, h->bits, sizeof(unsigned long long) * (size_t)H * WW, hipMemcpyDeviceToHost, s));
+    LG_HIP(h, hipStreamSynchronize(s));
+    double o[5];
+    *found = lg_host_orientation(h->bits_host, H, W, WW, o);
+    for (int i = 0; i < 5; i++) out[i] = *found ? (float)o[i] : NAN;
+    return LG_OK;
+}
+
+int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
+                  lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    return fail(h, LG_ERR_UNSUPPORTED, "lg_leaf_stats: not built yet");
+}
+
+int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
+    if (!h || !w) return LG_ERR_INVALID;
+    LG_HIP(h, hipSetDevice(h->device));
+    std::string err;
+    int rc = lg_cnn_upload(&h->cnn, w, &err);
+    if (rc) return fail(h, rc, err.c_str());
+    return LG_OK;
+}
+
+int lg_cnn_unload(lg_handle h) {
+    if (!h) return LG_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    lg_cnn_free(&h->cnn);
+    return LG_OK;
+}
+
+int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!patches || !logits || N <= 0) return fail(h, LG_ERR_INVALID, "lg_cnn_forward: bad argument");
+    if (!h->cnn.loaded) return fail(h, LG_ERR_NO_MODEL, "lg_cnn_forward: no model loaded (reference: ml_predictor is None)");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    std::string err;
+    ProfScope ps(h, "cnn", s);
+    int rc = lg_cnn_run(&h->cnn, patches, N, logits, s, &err);
+    if (rc) return fail(h, rc, err.c_str());
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
+                    float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, lg_grasp_result* results, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!results) return fail(h, LG_ERR_INVALID, "lg_select_grasp: results is null");
+    lg_params P;
+    if (pin) P = *pin; else lg_default_params(&P);
+    if (P.top_k < 1 || P.top_k > 64) return fail(h, LG_ERR_INVALID, "lg_select_grasp: top_k must be in [1,64]");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, B, H, W, P.top_k);
+    if (rc) return rc;
+    const bool use_cnn = h->cnn.loaded;
+    // all eight planes are needed when the CNN rescoring runs; otherwise only distance + traditional
+    float* maps[LG_NUM_MAPS];
+    for (int i = 0; i < LG_NUM_MAPS; i++) {
+        maps[i] = out_maps ? out_maps[i] : nullptr;
+        if (!maps[i] && (use_cnn || i == LG_MAP_DISTANCE || i == LG_MAP_TRADITIONAL)) {
+            rc = ensure_ws_map(h, i);
+            if (rc) return rc;
+            maps[i] = h->ws_maps[i];
+        }
+    }
+    uint8_t* valid = out_valid;
+    if (!valid) {
+        if (!h->ws_valid) LG_HIP(h, hipMalloc((void**)&h->ws_valid, (size_t)h->capB * h->capH * h->capW));
+        valid = h->ws_valid;
+    }
+    std::vector<float> theta(B);
+    rc = lg_score_maps(h, depth, mask, B, H, W, &P, maps, valid, theta.data(), stream_);
+    if (rc) return rc;
+    const int K = P.top_k;
+    {
+        ProfScope ps(h, "topk", s);
+        lg_launch_topk(maps[LG_MAP_TRADITIONAL], valid, depth, h->tilekeys, true, B, H, W, K, P.nms_min_distance, h->cand_xy,
+                       h->cand_n, h->cand_info, s);
+    }
+    if (use_cnn) {
+        {
+            ProfScope ps(h, "gather", s);
+            lg_launch_gather(depth, mask, maps, B, H, W, K, h->cand_xy, h->cand_n, h->patches, s);
+        }
+        std::string err;
+        ProfScope ps(h, "cnn", s);
+        rc = lg_cnn_run(&h->cnn, h->patches, B * K, h->logits, s, &err);
+        if (rc) return fail(h, rc, err.c_str());
+        LG_HIP(h, hipMemcpyAsync(h->h_logits, h->logits, sizeof(float) * B * K, hipMemcpyDeviceToHost, s));
+    }
+    LG_HIP(h, hipMemcpyAsync(h->h_xy, h->cand_xy, sizeof(int32_t) * B * K * 2, hipMemcpyDeviceToHost, s));
+    LG_HIP(h, hipMemcpyAsync(h->h_n, h->cand_n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    LG_HIP(h, hipMemcpyAsync(h->h_info, h->cand_info, sizeof(float) * B * K * 2, hipMemcpyDeviceToHost, s));
+    LG_HIP(h, hipStreamSynchronize(s));
+    LG_HIP(h, hipGetLastError());
+
+    const int WW = (W + 63) / 64;
+    for (int b = 0; b < B; b++) {
+        lg_grasp_result& R = results[b];
+        memset(&R, 0, sizeof(R));
+        R.theta = theta[b];
+        const int n = h->h_n[b];
+        R.n_candidates = n;
+        if (n <= 0) continue;  // reference: "No valid candidate points found" -> (None, None, None)
+        const int32_t* xy = h->h_xy + (size_t)b * K * 2;
+        const float* info = h->h_info + (size_t)b * K * 2;
+        int best = 0;
+        double best_score = info[0];  // candidate 0's traditional score (grasp_point_selector.py:205-206)
+        if (use_cnn && n > 1) {
+            for (int i = 0; i < n; i++) {
+                const int x = xy[2 * i], y = xy[2 * i + 1];
+                if (P.mask_is_bool && (x < 16 || y < 16 || x + 16 > W || y + 16 > H)) continue;
+                const double logit = h->h_logits[(size_t)b * K + i];
+                const double sg = 1.0 / (1.0 + exp(-logit));
+                const double ml = tanh(sg * 3.0) * 0.5 + 0.5;               // :133-136
+                const double conf = 1.0 - fabs(ml - 0.5) * 2.0;              // :222
+                const double wml = std::min(0.3, conf * 0.6);                // :223
+                const double comb = (1.0 - wml) * (double)info[2 * i] + wml * ml;  // :226
+                if (comb > best_score) { best_score = comb; best = i; R.ml_used = 1; }
+            }
+        }
+        R.found = 1;
+        R.x = xy[2 * best]; R.y = xy[2 * best + 1];
+        R.best_score = (float)best_score;
+        // get_3d_grasp_point (:152-180)
+        const double Z = info[2 * best + 1];
+        const double X = Z * ((double)R.x - (double)P.cx) / (double)P.f;
+        const double Y = Z * ((double)R.y - (double)P.cy) / (double)P.f;
+        R.X = (float)X; R.Y = (float)Y; R.Z = (float)Z;
+        // calculate_pre_grasp_point (:754-819)
+        const double nrm = sqrt(X * X + Y * Y + Z * Z);
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) { R.has_pre = 0; continue; }  // reference: exception -> None
+        const double dxn = X / nrm, dyn = Y / nrm;
+        const unsigned long long* hb = h->bits_host + (size_t)b * H * WW;
+        bool done = false;
+        for (int step = 0; step < 5 && !done; step++) {
+            // np.arange(0.05, 0.10, 0.01)[step] = start + step * ((start + delta) - start)
+            const double dist = 0.05 + (double)step * ((0.05 + 0.01) - 0.05);
+            const double tx = X - dxn * dist, ty = Y - dyn * dist, tz = Z;
+            const int u = (int)((tx * (double)P.f / tz) + (double)P.cx);
+            const int v = (int)((ty * (double)P.f / tz) + (double)P.cy);
+            if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
+            if (!lg_host_ellipse_hit(hb, H, W, WW, u, v, P.pregrasp_clearance)) {
+                const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
+                if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
+            }
+        }
+        if (!done) { R.pX = (float)(X - dxn * 0.10); R.pY = (float)(Y - dyn * 0.10); R.pZ = (float)Z; }
+        R.has_pre = 1;
+    }
+    return LG_OK;
+}
+
+}  // extern "C"

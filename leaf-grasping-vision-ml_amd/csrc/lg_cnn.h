@@ -1,0 +1,25 @@
+// GraspPointCNN (scripts/utils/ml_grasp_optimizer/model.py:5-128, eval mode, 'spatial' attention,
+// encoder_filters [64,128,256]) on gfx950: BN folded at load, 3x3 convs as implicit GEMM on
+// v_mfma_f32_32x32x2_f32 (exact fp32), fused bias+ReLU(+2x2 max-pool) epilogues.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/leafgrasp.h"
+
+struct LgCnn {
+    bool loaded = false;
+    float* wconv[6] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded
+    float* bconv[6] = {nullptr};
+    float* att_w = nullptr;       // [256]
+    float att_b = 0.f;
+    float* fcw[4] = {nullptr};    // transposed [in][out], BN folded (first three)
+    float* fcb[4] = {nullptr};
+    float* act[2] = {nullptr, nullptr};  // ping-pong activation planes, capN patches each
+    int capN = 0;
+};
+
+int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err);
+void lg_cnn_free(LgCnn* c);
+int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err);

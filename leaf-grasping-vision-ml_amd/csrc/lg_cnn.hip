@@ -1,0 +1,326 @@
+// GraspPointCNN forward on gfx950 (see lg_cnn.h).  Reference: scripts/utils/ml_grasp_optimizer/model.py:5-128.
+//
+// Conv layers: out[n][co][y][x] = relu(b[co] + sum_{ky,kx,ci} w[ky][kx][ci][co] * in[n][ci][y+ky-1][x+kx-1])
+// as D = W * X on v_mfma_f32_32x32x2_f32 with M = 32 output channels, N = 32 consecutive pixels of the
+// planar image, K = (tap, input channel) pairs.  A operand (weights) and B operand (im2col of an LDS
+// staged input tile) are one VGPR each; lanes 0..31 carry k, lanes 32..63 carry k+1.
+// Accumulator lane l holds pixel l&31 and channels (r&3)+8(r>>2)+4(l>>5): a store instruction writes 32
+// consecutive pixels of one channel row = one 128-byte line.
+#include "lg_cnn.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct LayerCfg { int cin, cinp, cout, wi; bool pool; };
+constexpr LayerCfg kLayers[6] = {
+    {9, 10, 64, 32, false}, {64, 64, 64, 32, true},   {64, 64, 128, 16, false},
+    {128, 128, 128, 16, true}, {128, 128, 256, 8, false}, {256, 256, 256, 8, true}};
+
+// WG = 256 threads = 4 waves; wave tile = 2 pixel-blocks x 2 channel-blocks (4 accumulators).
+// PP = pixel-block pairs per workgroup, CP = channel-block pairs per workgroup, PP*CP == 4.
+template <int CIN, int CINP, int COUT, int WI, bool POOL, int KC, int PP, int CP>
+__global__ __launch_bounds__(256) void lg_conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                         const float* __restrict__ bias, float* __restrict__ out) {
+    static_assert(PP * CP == 4, "4 waves per workgroup");
+    constexpr int PBROWS = 32 / WI > 0 ? 32 / WI : 1;   // image rows per 32-pixel block (WI=32:1, 16:2, 8:4)
+    constexpr int ROWS = 2 * PP * PBROWS;               // output rows per workgroup
+    constexpr int TR = ROWS + 2;                        // staged input rows (halo 1)
+    constexpr int TWID = WI + 2;
+    constexpr int COUT_T = 64 * CP;                     // output channels per workgroup
+    constexpr int IN_CH_STRIDE = TR * TWID + ((TR * TWID) % 2 == 0 ? 1 : 0);  // odd stride: halves hit other banks
+    __shared__ float s_in[KC * IN_CH_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * KC * COUT_T];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wp_i = wave % PP, wc_i = wave / PP;       // pixel-pair / channel-pair of this wave
+    constexpr int BANDS = WI / ROWS > 0 ? WI / ROWS : 1;
+    const int n = blockIdx.x / (BANDS * (COUT / COUT_T));
+    const int rem = blockIdx.x % (BANDS * (COUT / COUT_T));
+    const int band = rem % BANDS, ct = rem / BANDS;
+    const int y0 = band * ROWS;                          // first output row of the workgroup
+    const int co0 = ct * COUT_T;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // per-lane B-operand base offsets (within one channel plane of s_in) for the two pixel blocks
+    const int p = lane & 31, kh = lane >> 5;
+    int boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int pb = wp_i * 2 + i;                      // pixel block inside the workgroup tile
+        const int row = pb * PBROWS + p / WI, x = p % WI; // output pixel inside the tile
+        boff[i] = row * TWID + x;                         // + ky*TWID + kx addresses the tap
+    }
+    const int aoff = (wc_i * 64) + (lane & 31);           // A-operand: channel inside the tile (+32 for block 1)
+
+    const float* in_n = in + (size_t)n * CIN * WI * WI;
+    for (int c0 = 0; c0 < CINP; c0 += KC) {
+        __syncthreads();
+        // ---- stage input chunk [KC][TR][TWID] with zero padding (conv padding=1)
+        for (int idx = t; idx < KC * TR * TWID; idx += 256) {
+            const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
+            const int ry = r2 / TWID, rx = r2 % TWID;
+            const int gy = y0 - 1 + ry, gx = rx - 1, gc = c0 + ci;
+            float v = 0.0f;
+            if (gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI) v = in_n[((size_t)gc * WI + gy) * WI + gx];
+            s_in[ci * IN_CH_STRIDE + r2] = v;
+        }
+        // ---- stage weight chunk [9][KC][COUT_T] from packed [9][CINP][COUT]
+        for (int idx = t; idx < 9 * KC * (COUT_T / 4); idx += 256) {
+            const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
+            const int ci = rest % KC, tap = rest / KC;
+            const float4 v = *reinterpret_cast<const float4*>(wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q);
+            *reinterpret_cast<float4*>(&s_w[(tap * KC + ci) * COUT_T + 4 * q]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int k0 = 0; k0 < KC; k0 += 2) {
+                const int ci = k0 + kh;
+                const float a0 = s_w[(tap * KC + ci) * COUT_T + aoff];
+                const float a1 = s_w[(tap * KC + ci) * COUT_T + aoff + 32];
+                const float b0 = s_in[ci * IN_CH_STRIDE + boff[0] + ky * TWID + kx];
+                const float b1 = s_in[ci * IN_CH_STRIDE + boff[1] + ky * TWID + kx];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + ReLU (+ 2x2 max pool), planar NCHW store
+    constexpr int WO = POOL ? WI / 2 : WI;
+    float* out_n = out + (size_t)n * COUT * WO * WO;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + wc_i * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float bv = bias[co];
+            if (!POOL) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int pb = wp_i * 2 + i;
+                    const int pix = (y0 * WI) + pb * 32 + p;   // linear pixel index in the image plane
+                    out_n[(size_t)co * WI * WI + pix] = fmaxf(acc[i][j][r] + bv, 0.0f);
+                }
+            } else {
+                if (WI == 32) {
+                    // the wave's two pixel blocks are image rows y0+2a, y0+2a+1
+                    float v = fmaxf(acc[0][j][r], acc[1][j][r]);
+                    v = fmaxf(v, __shfl_xor(v, 1, 64));
+                    const int yo = (y0 + wp_i * 2) / 2, xo = p >> 1;
+                    if ((p & 1) == 0) out_n[((size_t)co * WO + yo) * WO + xo] = fmaxf(v + bv, 0.0f);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        float v = acc[i][j][r];
+                        v = fmaxf(v, __shfl_xor(v, WI, 64));   // row pair inside the pixel block
+                        v = fmaxf(v, __shfl_xor(v, 1, 64));
+                        const int pb = wp_i * 2 + i;
+                        const int row = y0 + pb * PBROWS + p / WI, x = p % WI;
+                        if (((p / WI) & 1) == 0 && (x & 1) == 0)
+                            out_n[((size_t)co * WO + (row >> 1)) * WO + (x >> 1)] = fmaxf(v + bv, 0.0f);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// attention (1x1 conv 256->1 + sigmoid), global average pool, classifier 256->256->128->64->1 (BN folded).
+// model.py:32-36,63-84,108-128.  One workgroup per patch.
+__global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, const float* __restrict__ att_w,
+                                                      float att_b, const float* __restrict__ w0,
+                                                      const float* __restrict__ b0, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, const float* __restrict__ w3,
+                                                      const float* __restrict__ b3, float* __restrict__ logits) {
+    __shared__ float s_a[4][16];
+    __shared__ float s_f[256], s_g[256];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* hn = h + (size_t)n * 256 * 16;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float4 x = *reinterpret_cast<const float4*>(hn + t * 16 + 4 * q);
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+    const float aw = att_w[t];
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        float s = aw * v[p];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) s_a[wave][p] = s;
+    }
+    __syncthreads();
+    float f = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        float z = s_a[0][p] + s_a[1][p] + s_a[2][p] + s_a[3][p] + att_b;
+        float a = 1.0f / (1.0f + expf(-z));
+        f += v[p] * a;
+    }
+    s_f[t] = f * (1.0f / 16.0f);
+    __syncthreads();
+    {   // 256 -> 256
+        float s = b0[t];
+        for (int c = 0; c < 256; c++) s += w0[c * 256 + t] * s_f[c];
+        s_g[t] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    if (t < 128) {  // 256 -> 128
+        float s = b1[t];
+        for (int c = 0; c < 256; c++) s += w1[c * 128 + t] * s_g[c];
+        s_f[t] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    if (t < 64) {  // 128 -> 64
+        float s = b2[t];
+        for (int c = 0; c < 128; c++) s += w2[c * 64 + t] * s_f[c];
+        s_g[t] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    if (t < 64) {  // 64 -> 1
+        float s = w3[t] * s_g[t];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (t == 0) logits[n] = s + b3[0];
+    }
+}
+
+template <int L, int KC, int PP, int CP>
+void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
+    constexpr LayerCfg cfg = kLayers[L];
+    constexpr int PBROWS = 32 / cfg.wi > 0 ? 32 / cfg.wi : 1;
+    constexpr int ROWS = 2 * PP * PBROWS;
+    constexpr int BANDS = cfg.wi / ROWS > 0 ? cfg.wi / ROWS : 1;
+    static_assert(ROWS <= cfg.wi && cfg.wi % ROWS == 0, "tile rows must divide the image");
+    const int grid = N * BANDS * (cfg.cout / (64 * CP));
+    hipLaunchKernelGGL((lg_conv3x3_kernel<cfg.cin, cfg.cinp, cfg.cout, cfg.wi, cfg.pool, KC, PP, CP>), dim3(grid), dim3(256), 0,
+                       s, in, c->wconv[L], c->bconv[L], out);
+}
+
+}  // namespace
+
+void lg_cnn_free(LgCnn* c) {
+    auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
+    for (int i = 0; i < 6; i++) { F(c->wconv[i]); F(c->bconv[i]); }
+    F(c->att_w);
+    for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
+    F(c->act[0]); F(c->act[1]);
+    c->capN = 0;
+    c->loaded = false;
+}
+
+static int upload(float** dst, const std::vector<float>& v, std::string* err) {
+    if (hipMalloc((void**)dst, v.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "lg_cnn_load: device allocation/copy failed";
+        return LG_ERR_HIP;
+    }
+    return LG_OK;
+}
+
+int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
+    lg_cnn_free(c);
+    const float eps = w->bn_eps > 0.f ? w->bn_eps : 1e-5f;
+    for (int L = 0; L < 6; L++) {
+        const LayerCfg cfg = kLayers[L];
+        if (!w->conv_w[L] || !w->conv_b[L] || !w->bn_g[L] || !w->bn_b[L] || !w->bn_m[L] || !w->bn_v[L]) {
+            *err = "lg_cnn_load: missing encoder tensor";
+            return LG_ERR_INVALID;
+        }
+        // fold eval-mode BatchNorm2d: y = (conv + b - mean) * g / sqrt(var + eps) + beta
+        std::vector<float> wp((size_t)9 * cfg.cinp * cfg.cout, 0.0f), bp(cfg.cout);
+        for (int co = 0; co < cfg.cout; co++) {
+            const double sc = (double)w->bn_g[L][co] / sqrt((double)w->bn_v[L][co] + (double)eps);
+            bp[co] = (float)(((double)w->conv_b[L][co] - (double)w->bn_m[L][co]) * sc + (double)w->bn_b[L][co]);
+            for (int ci = 0; ci < cfg.cin; ci++)
+                for (int tap = 0; tap < 9; tap++)
+                    wp[((size_t)tap * cfg.cinp + ci) * cfg.cout + co] =
+                        (float)((double)w->conv_w[L][((size_t)co * cfg.cin + ci) * 9 + tap] * sc);
+        }
+        int rc = upload(&c->wconv[L], wp, err);
+        if (rc) return rc;
+        rc = upload(&c->bconv[L], bp, err);
+        if (rc) return rc;
+    }
+    if (!w->att_w || !w->att_b) { *err = "lg_cnn_load: missing attention tensor"; return LG_ERR_INVALID; }
+    {
+        std::vector<float> aw(w->att_w, w->att_w + 256);
+        int rc = upload(&c->att_w, aw, err);
+        if (rc) return rc;
+        c->att_b = w->att_b[0];
+    }
+    const int dims[5] = {256, 256, 128, 64, 1};
+    for (int L = 0; L < 4; L++) {
+        const int fin = dims[L], fout = dims[L + 1];
+        if (!w->fc_w[L] || !w->fc_b[L]) { *err = "lg_cnn_load: missing classifier tensor"; return LG_ERR_INVALID; }
+        std::vector<float> wt((size_t)fin * fout), bt(fout);
+        for (int o = 0; o < fout; o++) {
+            double sc = 1.0, sh = 0.0;
+            if (L < 3) {
+                if (!w->fbn_g[L] || !w->fbn_b[L] || !w->fbn_m[L] || !w->fbn_v[L]) {
+                    *err = "lg_cnn_load: missing classifier BN tensor";
+                    return LG_ERR_INVALID;
+                }
+                sc = (double)w->fbn_g[L][o] / sqrt((double)w->fbn_v[L][o] + (double)eps);
+                sh = (double)w->fbn_b[L][o] - (double)w->fbn_m[L][o] * sc;
+            }
+            bt[o] = (float)((double)w->fc_b[L][o] * sc + sh);
+            for (int i = 0; i < fin; i++) wt[(size_t)i * fout + o] = (float)((double)w->fc_w[L][(size_t)o * fin + i] * sc);
+        }
+        int rc = upload(&c->fcw[L], wt, err);
+        if (rc) return rc;
+        rc = upload(&c->fcb[L], bt, err);
+        if (rc) return rc;
+    }
+    c->loaded = true;
+    return LG_OK;
+}
+
+int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
+    if (!c->loaded) { *err = "no model"; return LG_ERR_NO_MODEL; }
+    if (N > c->capN) {
+        hipStreamSynchronize(s);
+        if (c->act[0]) hipFree(c->act[0]);
+        if (c->act[1]) hipFree(c->act[1]);
+        c->act[0] = c->act[1] = nullptr;
+        const size_t per = 64 * 32 * 32;  // largest activation plane set per patch (conv1 output)
+        if (hipMalloc((void**)&c->act[0], (size_t)N * per * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&c->act[1], (size_t)N * per * sizeof(float)) != hipSuccess) {
+            *err = "lg_cnn_forward: activation workspace allocation failed";
+            c->capN = 0;
+            return LG_ERR_NOMEM;
+        }
+        c->capN = N;
+    }
+    float *A = c->act[0], *B = c->act[1];
+    //            L  KC PP CP
+    launch_conv<0, 10, 4, 1>(patches, c, A, N, s);   // 9 -> 64, 32x32
+    launch_conv<1, 8, 4, 1>(A, c, B, N, s);          // 64 -> 64, pool -> 16x16
+    launch_conv<2, 8, 4, 1>(B, c, A, N, s);          // 64 -> 128, 16x16
+    launch_conv<3, 8, 4, 1>(A, c, B, N, s);          // 128 -> 128, pool -> 8x8
+    launch_conv<4, 4, 1, 4>(B, c, A, N, s);          // 128 -> 256, 8x8
+    launch_conv<5, 4, 1, 4>(A, c, B, N, s);          // 256 -> 256, pool -> 4x4
+    hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_w, c->att_b, c->fcw[0], c->fcb[0], c->fcw[1],
+                       c->fcb[1], c->fcw[2], c->fcb[2], c->fcw[3], c->fcb[3], logits);
+    return LG_OK;
+}

@@ -1,0 +1,242 @@
+// Host-side leaf orientation on the bit-packed mask (product code; NOT the oracle).
+//
+// Semantics of GraspPointSelector.estimate_leaf_orientation (scripts/utils/grasp_point_selector.py:718-752):
+//   cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE) -> max by cv2.contourArea -> cv2.minAreaRect,
+//   "if size[0] < size[1]: angle += 90"  ==> direction of the LONGER side of the min-area rectangle of the
+//   largest outer contour, reported in (0, pi].
+// Implementation: run-length connected components (8-connectivity) on 64-bit rows, outer-border following
+// only when more than one component competes for "largest contour area", convex hull of the run end points
+// (identical to the hull of the contour), exhaustive min-area rectangle over hull edges.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lg_internal.h"
+
+namespace {
+
+struct Run { int y, x0, x1, parent; };  // inclusive span
+struct P2 { long long x, y; };
+
+inline bool bit_at(const unsigned long long* bits, int H, int W, int WW, int x, int y) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return false;
+    return (bits[(size_t)y * WW + (x >> 6)] >> (x & 63)) & 1ull;
+}
+
+int find_root(std::vector<Run>& r, int i) {
+    while (r[i].parent != i) {
+        r[i].parent = r[r[i].parent].parent;
+        i = r[i].parent;
+    }
+    return i;
+}
+
+// Shoelace area of the 8-connected outer border that starts at (sx, sy) (top-most/left-most pixel
+// of its component), traced through pixel centres like Suzuki-Abe border following.
+double outer_border_area(const unsigned long long* bits, int H, int W, int WW, int sx, int sy) {
+    // neighbours clockwise (screen coordinates, y down) starting at West
+    static const int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+    static const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    int first = -1;
+    for (int k = 0; k < 8; k++)
+        if (bit_at(bits, H, W, WW, sx + dx[k], sy + dy[k])) { first = k; break; }
+    if (first < 0) return 0.0;  // single pixel
+    const int fx = sx + dx[first], fy = sy + dy[first];
+    long long px = fx, py = fy, cx = sx, cy = sy;
+    double acc = 0.0;
+    long long lastx = 0, lasty = 0;
+    bool have_last = false;
+    long long firstx = sx, firsty = sy;
+    long long guard = 8LL * ((long long)H * W + 16);
+    for (;;) {
+        int dprev = 0;
+        for (int k = 0; k < 8; k++)
+            if (cx + dx[k] == px && cy + dy[k] == py) { dprev = k; break; }
+        long long nx = cx, ny = cy;
+        bool found = false;
+        for (int k = 1; k <= 8; k++) {
+            int d = (dprev - k) & 7;  // counter-clockwise from the previous pixel
+            if (bit_at(bits, H, W, WW, (int)cx + dx[d], (int)cy + dy[d])) {
+                nx = cx + dx[d];
+                ny = cy + dy[d];
+                found = true;
+                break;
+            }
+        }
+        if (have_last) acc += (double)lastx * (double)cy - (double)cx * (double)lasty;
+        lastx = cx; lasty = cy; have_last = true;
+        if (!found) break;
+        if (nx == sx && ny == sy && cx == fx && cy == fy) break;
+        px = cx; py = cy; cx = nx; cy = ny;
+        if (--guard < 0) break;
+    }
+    acc += (double)lastx * (double)firsty - (double)firstx * (double)lasty;  // close the polygon
+    return fabs(acc) * 0.5;
+}
+
+inline double crossp(const P2& o, const P2& a, const P2& b) {
+    return (double)(a.x - o.x) * (double)(b.y - o.y) - (double)(a.y - o.y) * (double)(b.x - o.x);
+}
+
+}  // namespace
+
+void lg_make_se_spans(int k, LgSeSpans* out) {
+    // cv2.getStructuringElement(MORPH_ELLIPSE, (k,k)): r = c = k/2, row i: dy = i - r,
+    // dx = round(c * sqrt((r*r - dy*dy) / (r*r))), ones in [max(c-dx,0), min(c+dx+1,k))
+    memset(out, 0, sizeof(*out));
+    if (k > 64) k = 64;
+    out->n = k;
+    out->anchor = k / 2;
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < k; i++) {
+        int j1 = 0, j2 = 0;
+        const int dy = i - r;
+        if (k == 1) {
+            j2 = 1;
+        } else if (abs(dy) <= r) {
+            int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));
+            j1 = std::max(c - dx, 0);
+            j2 = std::min(c + dx + 1, k);
+        }
+        if (j2 > j1) {
+            out->lo[i] = (signed char)(j1 - out->anchor);
+            out->hi[i] = (signed char)(j2 - 1 - out->anchor);
+        } else {
+            out->lo[i] = 1;
+            out->hi[i] = 0;
+        }
+    }
+}
+
+int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance) {
+    // dilated[v,u] != 0  <=>  some set pixel (u+dx, v+dy) with (dy,dx) in the (2c+1) ellipse
+    // (calculate_pre_grasp_point, grasp_point_selector.py:777-779,804)
+    LgSeSpans se;
+    lg_make_se_spans(2 * clearance + 1, &se);
+    for (int i = 0; i < se.n; i++) {
+        int y = v + i - se.anchor;
+        if (y < 0 || y >= H || se.lo[i] > se.hi[i]) continue;
+        int x0 = std::max(u + se.lo[i], 0), x1 = std::min(u + se.hi[i], W - 1);
+        for (int x = x0; x <= x1; x++)
+            if ((bits[(size_t)y * WW + (x >> 6)] >> (x & 63)) & 1ull) return 1;
+    }
+    return 0;
+}
+
+int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out) {
+    std::vector<Run> runs;
+    std::vector<int> row_start(H + 1, 0);
+    // ---- runs per row
+    for (int y = 0; y < H; y++) {
+        row_start[y] = (int)runs.size();
+        const unsigned long long* row = bits + (size_t)y * WW;
+        int x = 0;
+        bool in = false;
+        int start = 0;
+        for (int w = 0; w < WW; w++) {
+            unsigned long long v = row[w];
+            if (!in && v == 0) continue;
+            if (in && v == ~0ull && (w + 1) * 64 <= W) continue;
+            for (int b = 0; b < 64; b++) {
+                x = w * 64 + b;
+                if (x >= W) break;
+                bool s = (v >> b) & 1ull;
+                if (s && !in) { in = true; start = x; }
+                else if (!s && in) { in = false; runs.push_back({y, start, x - 1, (int)runs.size()}); }
+            }
+        }
+        if (in) runs.push_back({y, start, W - 1, (int)runs.size()});
+    }
+    row_start[H] = (int)runs.size();
+    if (runs.empty()) return 0;
+    // ---- union runs that touch (8-connectivity: overlap after growing by one pixel)
+    for (int y = 1; y < H; y++) {
+        int a = row_start[y - 1], ae = row_start[y], b = row_start[y], be = row_start[y + 1];
+        while (a < ae && b < be) {
+            if (runs[a].x1 + 1 >= runs[b].x0 && runs[b].x1 + 1 >= runs[a].x0) {
+                int ra = find_root(runs, a), rb = find_root(runs, b);
+                if (ra != rb) runs[std::max(ra, rb)].parent = std::min(ra, rb);
+            }
+            if (runs[a].x1 < runs[b].x1) a++; else b++;
+        }
+    }
+    // ---- components: root = first run in raster order (min index) => its (x0, y) is the border start
+    std::vector<int> roots;
+    for (int i = 0; i < (int)runs.size(); i++)
+        if (find_root(runs, i) == i) roots.push_back(i);
+    int best_root = roots[0];
+    if (roots.size() > 1) {
+        double best_area = -1.0;
+        for (int r : roots) {
+            double a = outer_border_area(bits, H, W, WW, runs[r].x0, runs[r].y);
+            if (a > best_area) { best_area = a; best_root = r; }
+        }
+    }
+    // ---- hull of the component's run end points (Andrew monotone chain, same orientation/ordering
+    //      convention as the documented spec: sort by x then y, counter-clockwise, collinear dropped)
+    std::vector<P2> pts;
+    for (int i = 0; i < (int)runs.size(); i++)
+        if (find_root(runs, i) == best_root) {
+            pts.push_back({runs[i].x0, runs[i].y});
+            if (runs[i].x1 != runs[i].x0) pts.push_back({runs[i].x1, runs[i].y});
+        }
+    std::sort(pts.begin(), pts.end(), [](const P2& a, const P2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    std::vector<P2> hull(2 * pts.size() + 2);
+    int n = (int)pts.size(), k = 0;
+    if (n < 3) {
+        for (int i = 0; i < n; i++) hull[k++] = pts[i];
+    } else {
+        for (int i = 0; i < n; i++) {
+            while (k >= 2 && crossp(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--;
+            hull[k++] = pts[i];
+        }
+        for (int i = n - 2, t = k + 1; i >= 0; i--) {
+            while (k >= t && crossp(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--;
+            hull[k++] = pts[i];
+        }
+        k--;
+    }
+    const int nh = k;
+    if (nh == 1) {
+        out[0] = M_PI / 2; out[1] = 0; out[2] = 0; out[3] = (double)hull[0].x; out[4] = (double)hull[0].y;
+        return 1;
+    }
+    double min_area = 1e300, bw = 0, bh = 0, bang = 0, bcx = 0, bcy = 0;
+    for (int i = 0; i < nh; i++) {
+        const P2 p = hull[i], q = hull[(i + 1) % nh];
+        double ex = (double)(q.x - p.x), ey = (double)(q.y - p.y), len = sqrt(ex * ex + ey * ey);
+        if (len == 0) continue;
+        double ux = ex / len, uy = ey / len;
+        double smin = 1e300, smax = -1e300, tmin = 1e300, tmax = -1e300;
+        for (int j = 0; j < nh; j++) {
+            double s = hull[j].x * ux + hull[j].y * uy;
+            double t = -hull[j].x * uy + hull[j].y * ux;
+            smin = std::min(smin, s); smax = std::max(smax, s);
+            tmin = std::min(tmin, t); tmax = std::max(tmax, t);
+        }
+        double area = (smax - smin) * (tmax - tmin);
+        if (area < min_area) {
+            double sc = 0.5 * (smin + smax), tc = 0.5 * (tmin + tmax);
+            min_area = area;
+            bw = smax - smin; bh = tmax - tmin;
+            bang = atan2(uy, ux);
+            bcx = sc * ux - tc * uy;
+            bcy = sc * uy + tc * ux;
+        }
+        if (nh == 2) break;
+    }
+    double ang = (bw < bh) ? bang + M_PI / 2 : bang;
+    ang = fmod(ang, M_PI);
+    if (ang <= 0) ang += M_PI;
+    out[0] = ang;
+    out[1] = std::max(bw, bh);
+    out[2] = std::min(bw, bh);
+    out[3] = bcx;
+    out[4] = bcy;
+    return 1;
+}

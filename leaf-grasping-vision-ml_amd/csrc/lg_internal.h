@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of liblgrasp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/leafgrasp.h"
+
+// ---- chamfer constants: 16.16 fixed point of OpenCV's DIST_L2 masks ("Distance transform")
+#define LG_A5 65536u        // 1.0
+#define LG_B5 91750u        // 1.4
+#define LG_C5 143976u       // 2.1969
+#define LG_A3 62587u        // 0.955
+#define LG_B3 89738u        // 1.3693
+#define LG_INIT0 0x1FFFFFFFu  // INT_MAX >> 2 : OpenCV's border initialiser
+#define LG_INF 0x3FFFFFFFu    // "no path yet" inside the DT sweeps (never wins against a real distance)
+#define LG_NOSRC 0x20000000u  // values >= this after the backward sweep mean: image has no source pixel
+
+// ---- final-kernel tile
+#define LG_TW 64
+#define LG_TH 32
+
+struct LgFrameParams {  // per frame, written by the host after contour analysis
+    float sin_t, cos_t;
+    int has_angle;
+    float theta;
+};
+
+struct LgSeSpans {  // run-length form of an elliptical structuring element (one span per SE row)
+    int n;          // rows
+    int anchor;     // k/2
+    signed char lo[64];  // first set column - anchor (inclusive); lo > hi => empty row
+    signed char hi[64];  // last set column - anchor (inclusive)
+};
+
+struct LgFinalArgs {
+    const float* depth;
+    const unsigned long long* bits;
+    const unsigned long long* stem_bits;
+    const uint32_t* maxfix;       // [B][2] max fixed-point d_in / d_out
+    const LgFrameParams* fp;      // [B]
+    float* maps[LG_NUM_MAPS];     // [B][H][W] each (may be null except DISTANCE/TRADITIONAL)
+    uint8_t* valid;               // [B][H][W] or null
+    unsigned long long* tilekeys; // [B][tiles]
+    int B, H, W, WW, tiles_x, tiles_y;
+    float cx, cy, f;
+    float w_approach, w_sdf, w_flat, w_access;
+    float sdf_w_interior, sdf_w_align, sdf_w_sdf, optimal_distance;
+    float access_w_dist, access_w_dir, flat_scale;
+    float iso_w_close, iso_w_wide, iso_ramp_top, iso_ramp_bottom, iso_inv_max;
+    float min_edge_distance, stem_valid_thresh;
+    float inv_maxd;
+    float k1[5];  // separable 1-D Gaussian (size 5, sigma 5/6)
+};
+
+// kernel launchers (lg_kernels.hip)
+void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s);
+void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,
+                         int bottom_start, const LgSeSpans& se, hipStream_t s);
+int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
+                 hipStream_t s);
+void lg_launch_final(const LgFinalArgs& a, hipStream_t s);
+void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
+                    bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,
+                    float* out_info, hipStream_t s);
+void lg_launch_gather(const float* depth, const uint8_t* mask, const float* const* maps_dev, int B, int H, int W, int k,
+                      const int32_t* xy, const int32_t* n, float* patches, hipStream_t s);
+
+// host-side contour analysis on the bit-packed mask (lg_contour.cpp)
+// returns 1 and fills out[0..4] = angle(rad,(0,pi]), major, minor, cx, cy ; 0 if the mask is empty
+int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out);
+// 1 if any set bit of `bits` lies under the (2c+1)^2 ellipse centred at (u,v)  (pre-grasp clearance probe)
+int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance);
+void lg_make_se_spans(int k, LgSeSpans* out);

@@ -1,0 +1,765 @@
+// gfx950 kernels of the per-pixel grasp-scoring path (score planes, fusion, top-k, patch gather).
+// Reference semantics: scripts/utils/grasp_point_selector.py (cited per kernel); design: DESIGN.md.
+#include "lg_internal.h"
+
+#include <limits.h>
+
+// ============================================================================ helpers
+__device__ __forceinline__ int lg_dpp_row_shr(int old, int v, int n) {
+    switch (n) {  // dpp_ctrl must be an immediate
+        case 1: return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(old, v, 0x112, 0xf, 0xf, false);
+        case 4: return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(old, v, 0x118, 0xf, 0xf, false);
+    }
+}
+// inclusive prefix-min over the 64 lanes of a wave (DPP row shifts + row broadcasts, gfx9 family)
+__device__ __forceinline__ int lg_wave_prefix_min(int v) {
+    const int id = INT_MAX;
+    v = min(v, lg_dpp_row_shr(id, v, 1));
+    v = min(v, lg_dpp_row_shr(id, v, 2));
+    v = min(v, lg_dpp_row_shr(id, v, 4));
+    v = min(v, lg_dpp_row_shr(id, v, 8));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1,3
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ int lg_wave_shr1(int old, int v) {  // lane i <- lane i-1 (lane 0 keeps old)
+    return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int lg_wave_shl1(int old, int v) {  // lane i <- lane i+1 (lane 63 keeps old)
+    return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned long long lg_wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t lg_wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint32_t w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t lg_orderable(float s) {  // monotone float -> uint32 map
+    if (s == 0.0f) s = 0.0f;  // -0.0 -> +0.0 (numpy sorts them as equal)
+    uint32_t b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ int lg_reflect(int v, int n) {  // torch 'reflect' index, clamped for safety
+    if (v < 0) v = -v;
+    if (v >= n) v = 2 * (n - 1) - v;
+    return v < 0 ? 0 : (v >= n ? n - 1 : v);
+}
+
+// ============================================================================ mask -> bit rows
+// bits[b][y][w] bit j = mask[b][y][64w + j] != 0.  One wave-ballot per 64 pixels.
+__global__ __launch_bounds__(256) void lg_pack_bits_kernel(const uint8_t* __restrict__ mask,
+                                                           unsigned long long* __restrict__ bits, int H, int W, int WW,
+                                                           long long nwords_total) {
+    const int lane = threadIdx.x & 63;
+    long long wid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;  // one 64-bit word per wave
+    const long long stride = ((long long)gridDim.x * 256) >> 6;
+    for (; wid < nwords_total; wid += stride) {
+        long long row = wid / WW;  // b*H + y
+        int w = (int)(wid - row * WW);
+        int x = w * 64 + lane;
+        uint8_t m = (x < W) ? mask[row * W + x] : (uint8_t)0;
+        unsigned long long b = __ballot(m != 0);
+        if (lane == 0) bits[wid] = b;
+    }
+}
+
+void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s) {
+    long long nwords = (long long)B * H * WW;
+    long long waves = nwords;
+    int blocks = (int)((waves + 3) / 4);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(lg_pack_bits_kernel, dim3(blocks), dim3(256), 0, s, mask, bits, H, W, WW, nwords);
+}
+
+// ============================================================================ stem penalty (binary dilation on bit rows)
+// stem = dilate(mask & bottom_region, ellipse k) & mask     (grasp_point_selector.py:688-701)
+// dilate(x,y) = OR over SE rows i, dx in [lo_i, hi_i] of src(x+dx, y+i-anchor)  (cv2.dilate, anchor k/2)
+struct LgU192 {
+    unsigned long long w0, w1, w2;  // bit p of the 192-bit row segment: w0 = bits 0..63 (word w-1), w1 = word w, w2 = word w+1
+};
+__device__ __forceinline__ LgU192 lg_shr192(LgU192 r, int s) {  // 0 < s < 64
+    LgU192 o;
+    o.w0 = (r.w0 >> s) | (r.w1 << (64 - s));
+    o.w1 = (r.w1 >> s) | (r.w2 << (64 - s));
+    o.w2 = (r.w2 >> s);
+    return o;
+}
+__device__ __forceinline__ LgU192 lg_or192(LgU192 a, LgU192 b) {
+    LgU192 o = {a.w0 | b.w0, a.w1 | b.w1, a.w2 | b.w2};
+    return o;
+}
+
+__global__ __launch_bounds__(256) void lg_stem_bits_kernel(const unsigned long long* __restrict__ bits,
+                                                           unsigned long long* __restrict__ stem, int H, int W, int WW,
+                                                           int bottom_start, LgSeSpans se) {
+    // one thread per (frame, y, word)
+    long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long per_frame = (long long)H * WW;
+    int b = blockIdx.y;
+    if (gid >= per_frame) return;
+    int y = (int)(gid / WW), w = (int)(gid % WW);
+    const unsigned long long* fb = bits + (long long)b * per_frame;
+    unsigned long long self = fb[(long long)y * WW + w];
+    unsigned long long acc = 0;
+    if (self != 0 && y + (se.n - 1 - se.anchor) >= bottom_start) {
+        for (int i = 0; i < se.n; i++) {
+            int yy = y + i - se.anchor;
+            int lo = se.lo[i], hi = se.hi[i];
+            if (lo > hi || yy < bottom_start || yy >= H) continue;
+            const unsigned long long* row = fb + (long long)yy * WW;
+            LgU192 r;
+            r.w0 = (w > 0) ? row[w - 1] : 0ull;
+            r.w1 = row[w];
+            r.w2 = (w + 1 < WW) ? row[w + 1] : 0ull;
+            if (!(r.w0 | r.w1 | r.w2)) continue;
+            // T bit p = OR_{j=0..n} R[p+j]
+            int n = hi - lo;
+            LgU192 t = r;
+            int covered = 1;  // t covers shifts [0, covered-1]
+            while (covered * 2 <= n + 1) {
+                t = lg_or192(t, lg_shr192(t, covered));
+                covered *= 2;
+            }
+            if (covered < n + 1) t = lg_or192(t, lg_shr192(t, n + 1 - covered));
+            // out bit b = T bit (64 + b + lo), lo in [-anchor, 0]
+            int sh = 64 + lo;  // 64-anchor .. 64
+            unsigned long long o = (sh == 64) ? t.w1 : ((t.w0 >> sh) | (t.w1 << (64 - sh)));
+            if (lo > 0) o = (t.w1 >> lo) | (t.w2 << (64 - lo));
+            acc |= o;
+        }
+    }
+    stem[(long long)b * per_frame + gid] = acc & self;
+}
+
+void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,
+                         int bottom_start, const LgSeSpans& se, hipStream_t s) {
+    long long per_frame = (long long)H * WW;
+    dim3 grid((unsigned)((per_frame + 255) / 256), B);
+    hipLaunchKernelGGL(lg_stem_bits_kernel, grid, dim3(256), 0, s, bits, stem, H, W, WW, bottom_start, se);
+}
+
+// ============================================================================ chamfer 5x5 distance transform
+// cv2.distanceTransform(src, DIST_L2, 5)  (grasp_point_selector.py:266, :529-530).
+// Row-sequential emulation of the two raster sweeps; each image row is one segmented-free min-plus
+// prefix scan across the workgroup (tmp[j] = min(u[j], tmp[j-1]+A)  ==  j*A + prefix-min(u[k]-k*A)).
+// All arithmetic is exact 16.16 integers, so any evaluation order gives OpenCV's integers.
+// grid = (2, B): blockIdx.x selects d_in (src = mask) or d_out (src = !mask).
+// The backward sweep is the same code on the 180-degree-rotated image.
+template <int T, int E, bool BWD>
+__global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ tmp,
+                                                   float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
+                                                   int W) {
+    constexpr int NW = T / 64;
+    constexpr int WP = T * E;
+    constexpr int D = 4;  // rows of global prefetch
+    __shared__ int s_wtot[2][NW];
+    __shared__ uint32_t s_halo[2][NW][4];
+    const int which = blockIdx.x;
+    const int frame = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const size_t fo = (size_t)frame * H * W;
+    const uint8_t* m = mask + fo;
+    uint32_t* tp = tmp + ((size_t)frame * 2 + which) * H * W;
+    float* dout = dist_out ? dist_out + fo : nullptr;
+    const int pc0 = BWD ? WP - (t + 1) * E : t * E;  // first physical column of this thread (multiple of E)
+    const bool vec_ok = (W % E) == 0;
+    const bool full = vec_ok && (pc0 + E <= W);
+    const int c0 = t * E;  // first logical column
+
+    uint32_t p1[E + 4], p2[E + 2];
+#pragma unroll
+    for (int i = 0; i < E + 4; i++) p1[i] = LG_INF;
+#pragma unroll
+    for (int i = 0; i < E + 2; i++) p2[i] = LG_INF;
+
+    // raw prefetch registers: forward = E mask bytes (packed in up to 2 dwords), backward = E dwords
+    constexpr int RAWN = BWD ? E : (E + 3) / 4;
+    uint32_t raw[D][RAWN];
+
+    auto load_row = [&](int r, uint32_t* dst) {  // r = logical row
+        const int prow = BWD ? H - 1 - r : r;
+        if (r >= H) return;
+        if (BWD) {
+            const uint32_t* src = tp + (size_t)prow * W + pc0;
+            if (full) {
+#pragma unroll
+                for (int q = 0; q < E / 4; q++) {
+                    uint4 v = *reinterpret_cast<const uint4*>(src + 4 * q);
+                    dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; k++) dst[k] = (pc0 + k < W) ? src[k] : LG_INF;
+            }
+        } else {
+            const uint8_t* src = m + (size_t)prow * W + pc0;
+            if (full) {
+                if (E == 4) {
+                    dst[0] = *reinterpret_cast<const uint32_t*>(src);
+                } else {
+                    uint2 v = *reinterpret_cast<const uint2*>(src);
+                    dst[0] = v.x; dst[1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RAWN; q++) dst[q] = 0;
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    // out-of-image columns behave as ordinary non-source pixels: encode as "src nonzero"
+                    uint32_t mb = (pc0 + k < W) ? (uint32_t)src[k] : (which ? 0u : 1u);
+                    dst[k >> 2] |= (mb & 0xffu) << (8 * (k & 3));
+                }
+            }
+        }
+    };
+
+    uint32_t mx = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) load_row(d, raw[d]);
+
+    for (int rb = 0; rb < H; rb += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int r = rb + d;
+            if (r < H) {
+                const int par = r & 1;
+                // ---- per-pixel upper bound ("init"): forward: source ? 0 : +inf ; backward: forward result
+                uint32_t init[E];
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    if (BWD) {
+                        init[k] = raw[d][E - 1 - k];
+                    } else {
+                        uint32_t mb = (raw[d][k >> 2] >> (8 * (k & 3))) & 0xffu;
+                        bool nz = which ? (mb == 0) : (mb != 0);
+                        init[k] = nz ? 0xFFFFFFFFu : 0u;
+                    }
+                }
+                load_row(r + D, raw[d]);  // refill the slot just consumed
+                // ---- contributions of the two previous rows
+                uint32_t v[E];
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    uint32_t u = p2[k] + LG_C5;
+                    u = min(u, p2[k + 2] + LG_C5);
+                    u = min(u, p1[k] + LG_C5);
+                    u = min(u, p1[k + 1] + LG_B5);
+                    u = min(u, p1[k + 2] + LG_A5);
+                    u = min(u, p1[k + 3] + LG_B5);
+                    u = min(u, p1[k + 4] + LG_C5);
+                    v[k] = min(u, init[k]);
+                }
+                // ---- same-row chain: thread-local, then across the workgroup
+#pragma unroll
+                for (int k = 1; k < E; k++) v[k] = min(v[k], v[k - 1] + LG_A5);
+                int mloc = (int)v[E - 1] - (int)((uint32_t)(c0 + E - 1) * LG_A5);
+                int pin = lg_wave_prefix_min(mloc);
+                if (lane == 63) s_wtot[par][wave] = pin;
+                int excl = lg_wave_shr1(INT_MAX, pin);
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++)
+                    if (w < wave) excl = min(excl, s_wtot[par][w]);
+                uint32_t cin = (t == 0) ? LG_INF : (uint32_t)(excl + (int)((uint32_t)(c0 - 1) * LG_A5));
+#pragma unroll
+                for (int k = 0; k < E; k++) v[k] = min(v[k], cin + (uint32_t)(k + 1) * LG_A5);
+                // ---- write back
+                const int prow = BWD ? H - 1 - r : r;
+                if (!BWD) {
+                    uint32_t* dst = tp + (size_t)prow * W + pc0;
+                    if (full) {
+#pragma unroll
+                        for (int q = 0; q < E / 4; q++)
+                            *reinterpret_cast<uint4*>(dst + 4 * q) =
+                                make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < E; k++)
+                            if (pc0 + k < W) dst[k] = v[k];
+                    }
+                } else {
+                    float o[E];
+#pragma unroll
+                    for (int k = 0; k < E; k++) {
+                        const int pc = pc0 + (E - 1 - k);
+                        uint32_t val = v[k];
+                        if (val >= LG_NOSRC) {  // image without any source pixel: OpenCV's border-initialised result
+                            int dd = min(min(pc + 1, W - pc), min(prow + 1, H - prow));
+                            val = LG_INIT0 + (uint32_t)dd * LG_A5;
+                        }
+                        if (pc < W) mx = max(mx, val);
+                        o[E - 1 - k] = (float)val * (1.0f / 65536.0f);
+                    }
+                    if (dout) {
+                        float* dst = dout + (size_t)prow * W + pc0;
+                        if (full) {
+#pragma unroll
+                            for (int q = 0; q < E / 4; q++)
+                                *reinterpret_cast<float4*>(dst + 4 * q) =
+                                    make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < E; k++)
+                                if (pc0 + k < W) dst[k] = o[k];
+                        }
+                    }
+                }
+                // ---- rotate row registers, exchange 2-column halos with the neighbouring threads
+#pragma unroll
+                for (int j = 0; j < E + 2; j++) p2[j] = p1[j + 1];
+                if (lane == 0) { s_halo[par][wave][0] = v[0]; s_halo[par][wave][1] = v[1]; }
+                if (lane == 63) { s_halo[par][wave][2] = v[E - 2]; s_halo[par][wave][3] = v[E - 1]; }
+                uint32_t l0 = (uint32_t)lg_wave_shr1((int)LG_INF, (int)v[E - 2]);
+                uint32_t l1 = (uint32_t)lg_wave_shr1((int)LG_INF, (int)v[E - 1]);
+                uint32_t r0 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[0]);
+                uint32_t r1 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[1]);
+                __syncthreads();
+                if (lane == 0 && wave > 0) { l0 = s_halo[par][wave - 1][2]; l1 = s_halo[par][wave - 1][3]; }
+                if (lane == 63 && wave < NW - 1) { r0 = s_halo[par][wave + 1][0]; r1 = s_halo[par][wave + 1][1]; }
+                p1[0] = l0; p1[1] = l1;
+#pragma unroll
+                for (int k = 0; k < E; k++) p1[2 + k] = v[k];
+                p1[E + 2] = r0; p1[E + 3] = r1;
+            }
+        }
+    }
+    if (BWD) {
+        mx = lg_wave_max_u32(mx);
+        if (lane == 0) atomicMax(&maxfix[frame * 2 + which], mx);
+    }
+}
+
+template <int T, int E>
+static void lg_dt_launch_t(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B,
+                           int H, int W, hipStream_t s) {
+    dim3 grid(2, B), block(T);
+    if (bwd)
+        hipLaunchKernelGGL((lg_dt5_kernel<T, E, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+    else
+        hipLaunchKernelGGL((lg_dt5_kernel<T, E, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+}
+
+int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
+                 hipStream_t s) {
+    // threads * 4 columns must cover the row
+    if (W <= 256) lg_dt_launch_t<64, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else if (W <= 512) lg_dt_launch_t<128, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else if (W <= 1024) lg_dt_launch_t<256, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else if (W <= 2048) lg_dt_launch_t<512, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else if (W <= 4096) lg_dt_launch_t<1024, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    else return -1;
+    return 0;
+}
+
+// ============================================================================ fused score planes
+// One pass producing sdf_score, approach, flatness, isolation, accessibility, stem, traditional and the
+// validity mask (grasp_point_selector.py:256-288) from depth + mask bits + distance_map (+ frame scalars).
+// Tile 64x32, 256 threads, each thread 4 consecutive pixels x 2 rows (16-byte stores per lane).
+__global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
+    constexpr int DW = 72;             // dm tile: cols tx0-4 .. tx0+67
+    constexpr int DH = LG_TH + 6;      // rows ty0-3 .. ty0+34
+    constexpr int GW = LG_TW + 2;      // g tile: cols tx0-1 .. tx0+64
+    constexpr int GH = LG_TH + 2;
+    __shared__ __attribute__((aligned(16))) float s_dm[DH * DW];
+    __shared__ float s_h[DH * GW];
+    __shared__ float s_g[GH * (GW + 2)];
+    __shared__ unsigned long long s_key[4];
+
+    // XCD-aware remap: each XCD (blockIdx % 8 group) walks a contiguous range of tiles
+    const int ntile = a.tiles_x * a.tiles_y;
+    const long long total = (long long)ntile * a.B;
+    long long id = blockIdx.x;
+    {
+        long long q = total / 8, r = total % 8;
+        long long xcd = id % 8, j = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int frame = (int)(id / ntile);
+    const int tile = (int)(id % ntile);
+    const int bx = tile % a.tiles_x, by = tile / a.tiles_x;
+    const int tx0 = bx * LG_TW, ty0 = by * LG_TH;
+    const int H = a.H, W = a.W, WW = a.WW;
+    const int t = threadIdx.x;
+    const size_t fo = (size_t)frame * H * W;
+    const float* depth = a.depth + fo;
+    const unsigned long long* bits = a.bits + (size_t)frame * H * WW;
+
+    // ---- stage dm = depth * mask over the extended tile (reflect padding of smooth_depth, image_processor.py:60)
+    const bool fast = ((W & 3) == 0) && (tx0 >= 4) && (tx0 + LG_TW + 4 <= W);
+    if (fast) {
+        for (int idx = t; idx < DH * (DW / 4); idx += 256) {
+            int er = idx / (DW / 4), g4 = idx % (DW / 4);
+            int y = lg_reflect(ty0 - 3 + er, H);
+            int x = tx0 - 4 + 4 * g4;
+            float4 d = *reinterpret_cast<const float4*>(depth + (size_t)y * W + x);
+            unsigned long long wbits = bits[(size_t)y * WW + (x >> 6)];
+            unsigned nib = (unsigned)(wbits >> (x & 63)) & 0xfu;
+            float4 o;
+            o.x = (nib & 1u) ? d.x : 0.0f;
+            o.y = (nib & 2u) ? d.y : 0.0f;
+            o.z = (nib & 4u) ? d.z : 0.0f;
+            o.w = (nib & 8u) ? d.w : 0.0f;
+            *reinterpret_cast<float4*>(&s_dm[er * DW + 4 * g4]) = o;
+        }
+    } else {
+        for (int idx = t; idx < DH * DW; idx += 256) {
+            int er = idx / DW, ec = idx % DW;
+            int y = lg_reflect(ty0 - 3 + er, H);
+            int x = lg_reflect(tx0 - 4 + ec, W);
+            float d = depth[(size_t)y * W + x];
+            unsigned long long wbits = bits[(size_t)y * WW + (x >> 6)];
+            s_dm[idx] = ((wbits >> (x & 63)) & 1ull) ? d : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- separable 5-tap Gaussian; g is stored at the *reflect-padded* coordinates the Sobel stage reads
+    //      (F.pad(g,(1,1,1,1),'reflect'), grasp_point_selector.py:648): g_ext(e) = G(reflect1(e)).
+    for (int idx = t; idx < DH * GW; idx += 256) {
+        int er = idx / GW, ec = idx % GW;
+        int x = lg_reflect(tx0 - 1 + ec, W);
+        int lc = x - (tx0 - 4);
+        lc = lc < 2 ? 2 : (lc > DW - 3 ? DW - 3 : lc);
+        const float* p = &s_dm[er * DW + lc - 2];
+        s_h[idx] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+    }
+    __syncthreads();
+    for (int idx = t; idx < GH * GW; idx += 256) {
+        int gr = idx / GW, ec = idx % GW;
+        int y = lg_reflect(ty0 - 1 + gr, H);
+        int lr = y - (ty0 - 3);
+        lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
+        const float* p = &s_h[(lr - 2) * GW + ec];
+        s_g[gr * (GW + 2) + ec] =
+            a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+    }
+    __syncthreads();
+
+    // ---- per-pixel planes
+    const int txi = t & 15, tyi = t >> 4;
+    const LgFrameParams fp = a.fp[frame];
+    const uint32_t mfi = a.maxfix[frame * 2 + 0], mfo = a.maxfix[frame * 2 + 1];
+    const float maxabs = fmaxf((float)mfi * (1.0f / 65536.0f), (float)mfo * (1.0f / 65536.0f));
+    const float inv_maxabs = __frcp_rn(maxabs);
+    const float inv_2s2 = __frcp_rn(2.0f * a.optimal_distance * a.optimal_distance);
+    const float f2 = a.f * a.f;
+    const float ramp_step = (H > 1) ? (a.iso_ramp_bottom - a.iso_ramp_top) / (float)(H - 1) : 0.0f;
+    const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
+    unsigned long long best = 0;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ly = tyi + 16 * rr;
+        const int y = ty0 + ly;
+        const int x0 = tx0 + 4 * txi;
+        if (y < H && x0 < W) {
+            const unsigned sh = (unsigned)(x0 & 63);
+            const unsigned mnib = (unsigned)(bits[(size_t)y * WW + bx] >> sh) & 0xfu;
+            const unsigned snib = (unsigned)(stemb[(size_t)y * WW + bx] >> sh) & 0xfu;
+            const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
+            float din[4];
+            const float* dsrc = a.maps[LG_MAP_DISTANCE] + fo + (size_t)y * W + x0;
+            if (vec) {
+                float4 v = *reinterpret_cast<const float4*>(dsrc);
+                din[0] = v.x; din[1] = v.y; din[2] = v.z; din[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) din[j] = (x0 + j < W) ? dsrc[j] : 0.0f;
+            }
+            const float* g0 = &s_g[(ly + 0) * (GW + 2) + 4 * txi];
+            const float* g1 = g0 + (GW + 2);
+            const float* g2 = g1 + (GW + 2);
+            float ga[6], gb[6], gc[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { ga[j] = g0[j]; gb[j] = g1[j]; gc[j] = g2[j]; }
+            const float dyp = (float)y - a.cy;
+            const int dyb = min(y + 1, H - y);
+            const float ramp = a.iso_ramp_top + ramp_step * (float)y;
+            float o_sdf[4], o_app[4], o_flat[4], o_iso[4], o_acc[4], o_stem[4], o_trad[4];
+            uint32_t vbytes = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = x0 + j;
+                const float m = ((mnib >> j) & 1u) ? 1.0f : 0.0f;
+                const float st = ((snib >> j) & 1u) ? 1.0f : 0.0f;
+                // flatness: Sobel cross-correlation on the smoothed plane, exp(-5 |grad|)   (:646-655)
+                float sx = (ga[j + 2] - ga[j]) + 2.0f * (gb[j + 2] - gb[j]) + (gc[j + 2] - gc[j]);
+                float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
+                float flat = __expf(-a.flat_scale * sqrtf(sx * sx + sy * sy));
+                // closed-form geometry planes                                           (:502-524, :569-593)
+                const float dxp = (float)x - a.cx;
+                const float r2 = dxp * dxp + dyp * dyp;
+                const float inv_r = r2 > 0.0f ? rsqrtf(r2) : 0.0f;
+                const float r = r2 * inv_r;
+                const float app = a.f * rsqrtf(r2 + f2) * m;
+                const float cosang = r2 > 0.0f ? dxp * inv_r : 1.0f;
+                const float acc = (a.access_w_dist * (1.0f - r * a.inv_maxd) + a.access_w_dir * cosang) * m;
+                // SDF / edge term                                                        (:526-567)
+                const float align = fp.has_angle ? fabsf(dxp * inv_r * fp.sin_t - dyp * inv_r * fp.cos_t) : 1.0f;
+                const float dd = din[j] - a.optimal_distance;
+                const float interior = __expf(-(dd * dd) * inv_2s2);
+                const float sdfn = din[j] * inv_maxabs;  // inside the mask d_out == 0
+                const float sdf = (a.sdf_w_interior * interior + a.sdf_w_align * align + a.sdf_w_sdf * sdfn) * m;
+                // degenerate isolation map: chamfer-3 transform of an image with no zero pixel (:595-633)
+                const int dbrd = min(min(x + 1, W - x), dyb);
+                const float dt3 = (float)(LG_INIT0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
+                const float s = dt3 * a.iso_inv_max;
+                const float iso = (a.iso_w_close * s + a.iso_w_wide * s) * ramp * m;
+                // fusion + validity                                                      (:272-288)
+                const float trad = (a.w_approach * app + a.w_sdf * sdf + a.w_flat * flat + a.w_access * acc) * (1.0f - st);
+                const bool valid = (din[j] > a.min_edge_distance) && (m > 0.0f) && (st < a.stem_valid_thresh);
+                o_sdf[j] = sdf; o_app[j] = app; o_flat[j] = flat; o_iso[j] = iso; o_acc[j] = acc; o_stem[j] = st;
+                o_trad[j] = trad;
+                if (valid) vbytes |= 1u << (8 * j);
+                if (x < W) {
+                    unsigned long long key =
+                        ((unsigned long long)lg_orderable(valid ? trad : 0.0f) << 32) | (uint32_t)(y * W + x);
+                    best = key > best ? key : best;
+                }
+            }
+            const size_t off = fo + (size_t)y * W + x0;
+            auto st4 = [&](int mi, const float* v) {
+                float* dst = a.maps[mi];
+                if (!dst) return;
+                if (vec) {
+                    *reinterpret_cast<float4*>(dst + off) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x0 + j < W) dst[off + j] = v[j];
+                }
+            };
+            st4(LG_MAP_SDF, o_sdf);
+            st4(LG_MAP_APPROACH, o_app);
+            st4(LG_MAP_FLATNESS, o_flat);
+            st4(LG_MAP_ISOLATION, o_iso);
+            st4(LG_MAP_ACCESS, o_acc);
+            st4(LG_MAP_STEM, o_stem);
+            st4(LG_MAP_TRADITIONAL, o_trad);
+            if (a.valid) {
+                if (vec) {
+                    *reinterpret_cast<uint32_t*>(a.valid + off) = vbytes;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x0 + j < W) a.valid[off + j] = (uint8_t)((vbytes >> (8 * j)) & 1u);
+                }
+            }
+        }
+    }
+    best = lg_wave_max_u64(best);
+    if ((t & 63) == 0) s_key[t >> 6] = best;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long k = s_key[0];
+        k = s_key[1] > k ? s_key[1] : k;
+        k = s_key[2] > k ? s_key[2] : k;
+        k = s_key[3] > k ? s_key[3] : k;
+        a.tilekeys[(size_t)frame * ntile + tile] = k;
+    }
+}
+
+void lg_launch_final(const LgFinalArgs& a, hipStream_t s) {
+    long long total = (long long)a.tiles_x * a.tiles_y * a.B;
+    hipLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
+}
+
+// ============================================================================ tile keys for an arbitrary (trad, valid) pair
+__global__ __launch_bounds__(256) void lg_tilekeys_kernel(const float* __restrict__ trad,
+                                                          const uint8_t* __restrict__ valid,
+                                                          unsigned long long* __restrict__ tilekeys, int H, int W,
+                                                          int tiles_x, int tiles_y) {
+    __shared__ unsigned long long s_key[4];
+    const int ntile = tiles_x * tiles_y;
+    const int frame = blockIdx.y, tile = blockIdx.x;
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    const size_t fo = (size_t)frame * H * W;
+    unsigned long long best = 0;
+    for (int i = threadIdx.x; i < LG_TW * LG_TH; i += 256) {
+        int x = bx * LG_TW + (i % LG_TW), y = by * LG_TH + (i / LG_TW);
+        if (x < W && y < H) {
+            size_t o = fo + (size_t)y * W + x;
+            float sc = valid[o] ? trad[o] : 0.0f;
+            unsigned long long key = ((unsigned long long)lg_orderable(sc) << 32) | (uint32_t)(y * W + x);
+            best = key > best ? key : best;
+        }
+    }
+    best = lg_wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = s_key[0];
+        for (int w = 1; w < 4; w++) k = s_key[w] > k ? s_key[w] : k;
+        tilekeys[(size_t)frame * ntile + tile] = k;
+    }
+}
+
+// ============================================================================ greedy spaced top-k
+// GraspPointSelector._get_candidate_points (grasp_point_selector.py:447-482) without the full sort:
+// repeat k times { argmax over not-yet-suppressed pixels (score desc, flat index desc);
+//                  suppress every pixel within Chebyshev distance 2*min_dist of the pick }.
+// Equivalent to the reference's greedy walk over the descending argsort (a pixel is accepted iff its
+// (2d+1)^2 window meets no earlier window, i.e. iff it is > 2d away from every accepted point).
+// One 1024-thread workgroup per frame; per-tile maxima live in LDS and only the <= 6 tiles touched by
+// a new suppression window are recomputed.
+#define LG_TOPK_T 1024
+#define LG_MAX_TILES 8192
+#define LG_MAX_K 64
+__global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restrict__ trad,
+                                                            const uint8_t* __restrict__ valid,
+                                                            const float* __restrict__ depth,
+                                                            const unsigned long long* __restrict__ tilekeys, int H,
+                                                            int W, int tiles_x, int tiles_y, int k, int md,
+                                                            int32_t* __restrict__ out_xy, int32_t* __restrict__ out_n,
+                                                            float* __restrict__ out_info) {
+    __shared__ unsigned long long s_keys[LG_MAX_TILES];
+    __shared__ unsigned long long s_best;
+    __shared__ int s_cx[LG_MAX_K], s_cy[LG_MAX_K];
+    const int frame = blockIdx.x;
+    const int ntile = tiles_x * tiles_y;
+    const int t = threadIdx.x;
+    const size_t fo = (size_t)frame * H * W;
+    const int sup = 2 * md;
+    for (int i = t; i < ntile; i += LG_TOPK_T) s_keys[i] = tilekeys[(size_t)frame * ntile + i];
+    if (t == 0) s_best = 0;
+    __syncthreads();
+    int n = 0;
+    for (int r = 0; r < k; r++) {
+        unsigned long long b = 0;
+        for (int i = t; i < ntile; i += LG_TOPK_T) b = s_keys[i] > b ? s_keys[i] : b;
+        b = lg_wave_max_u64(b);
+        if ((t & 63) == 0 && b) atomicMax(&s_best, b);
+        __syncthreads();
+        const unsigned long long bk = s_best;
+        if (bk == 0) break;  // every pixel is suppressed
+        const int idx = (int)(uint32_t)(bk & 0xffffffffull);
+        const int px = idx % W, py = idx / W;
+        if (t == 0) {
+            s_cx[r] = px; s_cy[r] = py;
+            out_xy[((size_t)frame * k + r) * 2 + 0] = px;
+            out_xy[((size_t)frame * k + r) * 2 + 1] = py;
+            if (out_info) {
+                out_info[((size_t)frame * k + r) * 2 + 0] = trad[fo + idx];
+                out_info[((size_t)frame * k + r) * 2 + 1] = depth ? depth[fo + idx] : 0.0f;
+            }
+        }
+        n = r + 1;
+        // tiles touched by the new suppression window
+        const int tx_lo = max(px - sup, 0) / LG_TW, tx_hi = min(px + sup, W - 1) / LG_TW;
+        const int ty_lo = max(py - sup, 0) / LG_TH, ty_hi = min(py + sup, H - 1) / LG_TH;
+        const int ntx = tx_hi - tx_lo + 1, nty = ty_hi - ty_lo + 1;
+        const int naff = ntx * nty;
+        __syncthreads();  // s_cx/s_cy visible; everyone has read s_best
+        if (t == 0) s_best = 0;
+        if (t < naff) s_keys[(ty_lo + t / ntx) * tiles_x + tx_lo + t % ntx] = 0;
+        __syncthreads();
+        const int chunks = naff * (LG_TW * LG_TH / LG_TOPK_T);  // chunks of 1024 pixels, 2 per tile
+        for (int c = 0; c < chunks; c++) {
+            const int ta = c / (LG_TW * LG_TH / LG_TOPK_T);
+            const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
+            const int li = (c % (LG_TW * LG_TH / LG_TOPK_T)) * LG_TOPK_T + t;
+            const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
+            unsigned long long key = 0;
+            if (x < W && y < H) {
+                bool dead = false;
+                for (int q = 0; q <= r; q++) dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
+                if (!dead) {
+                    size_t o = fo + (size_t)y * W + x;
+                    float sc = valid[o] ? trad[o] : 0.0f;
+                    key = ((unsigned long long)lg_orderable(sc) << 32) | (uint32_t)(y * W + x);
+                }
+            }
+            key = lg_wave_max_u64(key);
+            if ((t & 63) == 0 && key) atomicMax(&s_keys[tile], key);
+        }
+        __syncthreads();
+    }
+    if (t == 0) out_n[frame] = n;
+}
+
+void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
+                    bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,
+                    float* out_info, hipStream_t s) {
+    int tiles_x = (W + LG_TW - 1) / LG_TW, tiles_y = (H + LG_TH - 1) / LG_TH;
+    if (!keys_ready)
+        hipLaunchKernelGGL(lg_tilekeys_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, s, trad, valid, tilekeys, H, W,
+                           tiles_x, tiles_y);
+    hipLaunchKernelGGL(lg_topk_kernel, dim3(B), dim3(LG_TOPK_T), 0, s, trad, valid, depth, tilekeys, H, W, tiles_x,
+                       tiles_y, k, min_dist, out_xy, out_n, out_info);
+}
+
+// ============================================================================ 9-channel patch gather
+// get_ml_score feature assembly (grasp_point_selector.py:59-127): 32x32 window [y-16,y+16) x [x-16,x+16),
+// replicate-padded (:392-445); channel 0 depth and channels 2..8 (sdf, approach, flatness, isolation,
+// distance, accessibility, stem) are min-max normalised per patch when max > min; channel 1 = raw mask.
+struct LgGatherMaps { const float* p[7]; };
+__global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict__ depth,
+                                                        const uint8_t* __restrict__ mask, LgGatherMaps maps, int H,
+                                                        int W, int k, const int32_t* __restrict__ xy,
+                                                        const int32_t* __restrict__ n, float* __restrict__ patches) {
+    __shared__ float s_mn[4], s_mx[4];
+    const int ci = blockIdx.x, frame = blockIdx.y;
+    const int t = threadIdx.x;
+    float* outp = patches + ((size_t)frame * k + ci) * 9 * 1024;
+    if (ci >= n[frame]) {
+        for (int c = 0; c < 9; c++)
+            for (int i = t; i < 1024; i += 256) outp[c * 1024 + i] = 0.0f;
+        return;
+    }
+    const int px = xy[((size_t)frame * k + ci) * 2], py = xy[((size_t)frame * k + ci) * 2 + 1];
+    const size_t fo = (size_t)frame * H * W;
+    for (int c = 0; c < 9; c++) {
+        float v[4];
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int i = t + 256 * q;
+            int yy = py - 16 + (i >> 5), xx = px - 16 + (i & 31);
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            size_t o = fo + (size_t)yy * W + xx;
+            float val = (c == 0) ? depth[o] : (c == 1) ? (mask[o] ? 1.0f : 0.0f) : maps.p[c - 2][o];
+            v[q] = val;
+            mn = fminf(mn, val);
+            mx = fmaxf(mx, val);
+        }
+        if (c != 1) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                mn = fminf(mn, __shfl_xor(mn, o, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            }
+            __syncthreads();  // previous channel's readers are done
+            if ((t & 63) == 0) { s_mn[t >> 6] = mn; s_mx[t >> 6] = mx; }
+            __syncthreads();
+            mn = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+            mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+            if (mx > mn) {
+                const float range = mx - mn;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = (v[q] - mn) / range;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) outp[c * 1024 + t + 256 * q] = v[q];
+    }
+}
+
+void lg_launch_gather(const float* depth, const uint8_t* mask, const float* const* maps_host, int B, int H, int W, int k,
+                      const int32_t* xy, const int32_t* n, float* patches, hipStream_t s) {
+    LgGatherMaps gm;
+    for (int i = 0; i < 7; i++) gm.p[i] = maps_host[i];
+    hipLaunchKernelGGL(lg_gather_kernel, dim3(k, B), dim3(256), 0, s, depth, mask, gm, H, W, k, xy, n, patches);
+}
