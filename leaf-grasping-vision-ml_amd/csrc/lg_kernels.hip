@@ -173,7 +173,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     const size_t fo = (size_t)frame * H * W;
     const uint8_t* m = mask + fo;
     uint32_t* tp = tmp + ((size_t)frame * 2 + which) * H * W;
-    float* dout = dist_out ? dist_out + fo : nullptr;
+    float* dout = (dist_out && which == 0) ? dist_out + fo : nullptr;  // only d_in is a contract plane
     const int pc0 = BWD ? WP - (t + 1) * E : t * E;  // first physical column of this thread (multiple of E)
     const bool vec_ok = (W % E) == 0;
     const bool full = vec_ok && (pc0 + E <= W);
