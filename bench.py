@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the full grasp-scoring hot path on synthetic 1080p depth+mask frames.
+
+Workload (BASELINE.json configs[1]): 1080x1920 depth f32 + binary leaf mask, full per-pixel score planes
+(8 f32 maps + validity), top-20 spaced candidates, 9-channel patch gather, GraspPointCNN (fp32) rescoring
+of the 20 candidates, 3-D / pre-grasp points -- i.e. GraspPointSelector.select_grasp_point for every frame.
+One "step" = one pass of that path over one batch of --batch frames already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Frames are independent: with N ranks every rank scores its own batch (weak scaling, no data-path
+collective; torch.distributed is used only for the timing barrier and the max-over-ranks reduction).
+Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# compulsory HBM bytes per pixel of the dominant ("final" = fused score-plane) kernel:
+#   read depth f32 4 + distance_map f32 4 + mask bits 1/8 + stem bits 1/8; write 7 f32 planes 28 + valid u8 1
+FINAL_BYTES_PER_PX = 4 + 4 + 0.125 + 0.125 + 28 + 1
+PATH_BYTES_PER_PX = 38.0  # whole-path compulsory traffic per pixel
+
+
+def make_frames(B, H, W, n_distinct=4):
+    from oracle import lg_oracle as O  # synthetic scene generator only (inputs, not the measured path)
+
+    masks, depths, P = [], [], None
+    for s in range(min(B, n_distinct)):
+        labels, depth, P = O.synthetic_scene(H, W, seed=100 + s)
+        masks.append(labels == 1)
+        depths.append(depth)
+    reps = (B + len(masks) - 1) // len(masks)
+    m = np.stack((masks * reps)[:B])
+    d = np.stack((depths * reps)[:B])
+    return m, d, P
+
+
+def cpu_baseline(H, W, P, params, n_frames):
+    """Restated reference-equivalent CPU path (oracle, NumPy/torch-CPU + C chamfer): same work as
+    scripts/utils/grasp_point_selector.py::select_grasp_point.  NOT the reference's own timing
+    (OpenCV / scikit-fmm are absent from this image)."""
+    from oracle import lg_oracle as O
+
+    ref = O.RefGraspPointSelector(cnn=lambda x: O.cnn_forward(params, x))
+    ref.set_camera_params(P)
+    times = []
+    for s in range(n_frames + 1):
+        labels, depth, _ = O.synthetic_scene(H, W, seed=100 + (s % 4))
+        mask = (labels == 1).astype(np.uint8)
+        t0 = time.perf_counter()
+        ref.select_grasp_point(mask, depth, tie_rule="numpy")
+        dt = time.perf_counter() - t0
+        if s > 0:  # first frame is warm-up
+            times.append(dt)
+    return times
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-cnn", action="store_true", help="CV-only (diagnostic; NOT the headline config)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import leafgrasp_amd as L
+    from leafgrasp_amd._lib import lib
+    from oracle import lg_oracle as O  # closed-form CNN weights (inputs) + cpu_baseline leg only
+
+    H, W, B = args.height, args.width, args.batch
+    masks_np, depths_np, P = make_frames(B, H, W)
+    masks = torch.from_numpy(masks_np).to(dev)
+    depths = torch.from_numpy(depths_np).to(dev)
+    sel = L.GraspPointSelector(dev, load_model=False)
+    sel.set_camera_params(P)
+    params = O.cnn_closed_form_params(seed=0)
+    if not args.no_cnn:
+        sel.set_cnn_state_dict(params)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    lib.lg_profile_enable(sel._h, 1)
+    for _ in range(args.warmup):
+        sel.select_grasp_points_batch(masks, depths)
+    lib.lg_profile_enable(sel._h, 1)  # reset counters, keep the event pool
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = sel.select_grasp_points_batch(masks, depths)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(r[0] is not None for r in res), "synthetic frames must yield a grasp point"
+
+    # per-kernel device time (HIP events recorded on the launch stream inside the library)
+    kern = {}
+    for name in ("prep", "stem", "dt_fwd", "dt_bwd", "final", "topk", "gather", "cnn"):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        lib.lg_profile_read(sel._h, name.encode(), C.byref(n), C.byref(ms))
+        if n.value:
+            kern[name] = {"launches": n.value, "avg_ms": ms.value / n.value}
+    lib.lg_profile_enable(sel._h, 0)
+
+    if rank == 0:
+        frames = world * B * args.steps
+        fps = frames / elapsed
+        px = B * H * W
+        out = {
+            "metric": "frames/sec (1080p depth+mask) grasp scoring",
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{H}x{W} depth+mask, 8 score planes + valid + top-20 NMS + "
+                                   f"{'CV only' if args.no_cnn else 'GraspPointCNN fp32 rescoring of 20 candidates'}",
+                       "frames_per_step_per_gpu": B, "height": H, "width": W,
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "path_hbm_frac": round(fps / world * PATH_BYTES_PER_PX * H * W / (HBM_PEAK_GBS * 1e9), 5),
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},
+        }
+        if "final" in kern:
+            achieved = FINAL_BYTES_PER_PX * px / (kern["final"]["avg_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                               "traffic": None, "bytes_per_px": FINAL_BYTES_PER_PX}
+        if "cnn" in kern and not args.no_cnn:
+            fl = 312.83e6 * 20 * B
+            tf = fl / (kern["cnn"]["avg_ms"] * 1e-3) / 1e12
+            out["mfma"] = {"kernel": "lg_conv3x3_kernel x6 + head", "achieved": round(tf, 2), "peak": 157.3,
+                           "unit": "TFLOP/s", "frac": round(tf / 157.3, 4)}
+        if world == 1 and args.cpu_frames > 0:
+            times = cpu_baseline(H, W, P, params, args.cpu_frames)
+            out["cpu_baseline"] = {
+                "value": round(len(times) / sum(times), 4), "unit": "frames/s",
+                "cores": int(torch.get_num_threads()), "kind": "port",
+                "sample": f"{len(times)} synthetic {H}x{W} frames through oracle/lg_oracle.py "
+                          f"(restated NumPy/torch-CPU + C chamfer path, numpy argsort, 20 batch-1 CNN forwards); "
+                          f"os.cpu_count()={os.cpu_count()}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
