@@ -114,7 +114,11 @@ class GraspPointSelector:
             depth_tensor = torch.from_numpy(depth_tensor)
         is_bool = leaf_mask.dtype == torch.bool
         m = leaf_mask.to(self.device)
-        m = (m != 0).to(torch.uint8).contiguous()
+        if is_bool:
+            m = m.contiguous().view(torch.uint8)  # bool storage is one 0/1 byte: reinterpret, no kernel
+        elif m.dtype != torch.uint8:
+            m = (m != 0).to(torch.uint8)
+        m = m.contiguous()
         d = depth_tensor.to(self.device, torch.float32).contiguous()
         if m.dim() == 2:
             m, d = m.unsqueeze(0), d.unsqueeze(0)
