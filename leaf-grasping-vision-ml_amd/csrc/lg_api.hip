@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "lg_cnn.h"
+#include "lg_leaf.h"
 #include "lg_internal.h"
 
 #define LG_VERSION_STR "leafgrasp-gfx950 0.1"
@@ -43,6 +44,7 @@ struct lg_ctx {
     int32_t *h_xy = nullptr, *h_n = nullptr;  // pinned
     float *h_info = nullptr, *h_logits = nullptr;
     LgCnn cnn;
+    LgLeafWs* leaf = nullptr;
     bool prof_on = false;
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -233,6 +235,7 @@ int lg_destroy(lg_handle h) {
     hipDeviceSynchronize();
     free_ws(h);
     lg_cnn_free(&h->cnn);
+    lg_leaf_free(h->leaf);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
@@ -420,7 +423,15 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
 int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
                   lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, void* stream_) {
     if (!h) return LG_ERR_INVALID;
-    return fail(h, LG_ERR_UNSUPPORTED, "lg_leaf_stats: not built yet");
+    if (!labels || !depth || !stats || !n_leaves || !extrema || H < 1 || W < 1 || max_leaves < 1)
+        return fail(h, LG_ERR_INVALID, "lg_leaf_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    std::string err;
+    ProfScope ps(h, "leaf", s);
+    int rc = lg_leaf_run(h->leaf, labels, depth, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, s, &err);
+    if (rc) return fail(h, rc, err.c_str());
+    return LG_OK;
 }
 
 int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {

@@ -1,0 +1,484 @@
+// Leaf-selection statistics on gfx950: the per-leaf full-frame passes of
+// OptimalLeafSelector.select_optimal_leaf (scripts/utils/leaf_scorer.py:25-203) in a fixed number of
+// streaming passes over the int16 label image + f32 depth:
+//   * label presence bitmap -> compact slot per id (torch.unique, :32)
+//   * per-slot area, sum x, sum y (int64, exact), sum depth, sum ray length (f64), border flag, first leaf pixel
+//   * per-slot exact median depth by 4x8-bit radix select on order-preserving keys (+1 successor pass for
+//     even counts)  (np.median, :41-47)
+//   * global clutter extrema (:66-71): exact squared Euclidean distance to the nearest leaf pixel
+//     (column scan + per-row monotone-minima divide and conquer), arg-max with first-occurrence ties.
+#include "lg_leaf.h"
+
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#define LGL_MAXL 64          // labels per frame supported by the LDS histograms
+#define LGL_RUN 16           // consecutive pixels per thread (run-length aggregation before atomics)
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2key(float f) {  // order-preserving float -> uint32
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+// ---------------------------------------------------------------- presence bitmap of ids 1..32767
+__global__ __launch_bounds__(256) void k_presence(const int16_t* __restrict__ lab, long long n,
+                                                  unsigned long long* __restrict__ pres) {
+    __shared__ unsigned long long s_p[512];
+    for (int i = threadIdx.x; i < 512; i += 256) s_p[i] = 0;
+    __syncthreads();
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    int last = 0;
+    for (; i < n; i += stride) {
+        int id = lab[i];
+        if (id > 0 && id != last) {
+            unsigned long long bit = 1ull << (id & 63);
+            if (!(s_p[id >> 6] & bit)) atomicOr(&s_p[id >> 6], bit);
+            last = id;
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < 512; w += 256)
+        if (s_p[w]) atomicOr(&pres[w], s_p[w]);
+}
+
+// prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1))
+__global__ void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < 512; w++) {
+            pre[w] = acc;
+            acc += __popcll(pres[w]);
+        }
+        *nlab = acc;
+    }
+}
+
+__device__ __forceinline__ int slot_of(int id, const unsigned long long* pres, const int* pre) {
+    unsigned long long w = pres[id >> 6];
+    return pre[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull));
+}
+
+struct LeafAcc {  // device accumulators, one per slot
+    unsigned long long area;
+    long long sum_x, sum_y;
+    double sum_depth, sum_ray;
+    int border;
+    int pad;
+};
+
+// ---------------------------------------------------------------- per-slot sums
+__global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ lab, const float* __restrict__ depth,
+                                                    int H, int W, const unsigned long long* __restrict__ pres,
+                                                    const int* __restrict__ pre, float cx, float cy, float f,
+                                                    LeafAcc* __restrict__ acc, unsigned long long* __restrict__ first_leaf) {
+    __shared__ LeafAcc s_acc[LGL_MAXL];
+    __shared__ unsigned long long s_first;
+    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) {
+        s_acc[i].area = 0; s_acc[i].sum_x = 0; s_acc[i].sum_y = 0;
+        s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0;
+    }
+    if (threadIdx.x == 0) s_first = ~0ull;
+    __syncthreads();
+    const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
+    const long long nruns = (long long)H * runs_per_row;
+    const double f2 = (double)f * (double)f;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
+        const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
+        const int x1 = min(x0 + LGL_RUN, W);
+        int cur = 0;
+        unsigned long long a = 0; long long sx = 0; double sd = 0.0, sr = 0.0; int bd = 0;
+        const double dy = (double)y - (double)cy;
+        for (int x = x0; x <= x1; x++) {
+            int id = (x < x1) ? (int)lab[(size_t)y * W + x] : 0;
+            if (id < 0) id = 0;
+            if (id != cur) {
+                if (cur > 0 && a) {
+                    int s = slot_of(cur, pres, pre);
+                    if (s < LGL_MAXL) {
+                        atomicAdd(&s_acc[s].area, a);
+                        atomicAdd((unsigned long long*)&s_acc[s].sum_x, (unsigned long long)sx);
+                        atomicAdd((unsigned long long*)&s_acc[s].sum_y, (unsigned long long)((long long)a * y));
+                        atomicAdd(&s_acc[s].sum_depth, sd);
+                        atomicAdd(&s_acc[s].sum_ray, sr);
+                        if (bd) atomicOr(&s_acc[s].border, 1);
+                    }
+                }
+                cur = id; a = 0; sx = 0; sd = 0.0; sr = 0.0; bd = 0;
+            }
+            if (id > 0) {
+                if (a == 0) atomicMin(&s_first, (unsigned long long)y * W + x);
+                a++;
+                sx += x;
+                sd += (double)depth[(size_t)y * W + x];
+                const double dx = (double)x - (double)cx;
+                sr += sqrt(dx * dx + dy * dy + f2);
+                bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) {
+        if (s_acc[i].area) {
+            atomicAdd(&acc[i].area, s_acc[i].area);
+            atomicAdd((unsigned long long*)&acc[i].sum_x, (unsigned long long)s_acc[i].sum_x);
+            atomicAdd((unsigned long long*)&acc[i].sum_y, (unsigned long long)s_acc[i].sum_y);
+            atomicAdd(&acc[i].sum_depth, s_acc[i].sum_depth);
+            atomicAdd(&acc[i].sum_ray, s_acc[i].sum_ray);
+            if (s_acc[i].border) atomicOr(&acc[i].border, 1);
+        }
+    }
+    if (threadIdx.x == 0 && s_first != ~0ull) atomicMin(first_leaf, s_first);
+}
+
+// ---------------------------------------------------------------- radix select (median)
+struct SelState {       // per slot
+    uint32_t prefix;    // key bits fixed so far (high bits)
+    uint32_t rank;      // remaining 0-based rank inside the current prefix bucket
+    uint32_t n_le;      // (after the last pass) number of elements <= selected key
+    uint32_t key;       // selected key (after the last pass)
+};
+
+// histogram of digit `pass` (3 = most significant byte) among elements whose higher bytes match the prefix
+__global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, const float* __restrict__ depth, int H, int W,
+                                              const unsigned long long* __restrict__ pres, const int* __restrict__ pre,
+                                              const SelState* __restrict__ st, int pass, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[LGL_MAXL * 256];
+    for (int i = threadIdx.x; i < LGL_MAXL * 256; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const int shift = 8 * pass;
+    const uint32_t himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
+    const long long nruns = (long long)H * runs_per_row;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
+        const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
+        const int x1 = min(x0 + LGL_RUN, W);
+        int cur_id = 0, cur_slot = -1, cur_bin = -1;
+        uint32_t cnt = 0, cur_prefix = 0;
+        for (int x = x0; x < x1; x++) {
+            int id = (int)lab[(size_t)y * W + x];
+            if (id <= 0) continue;
+            if (id != cur_id) {
+                if (cnt) { atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt); cnt = 0; }
+                cur_id = id;
+                cur_slot = slot_of(id, pres, pre);
+                cur_bin = -1;
+                if (cur_slot < LGL_MAXL) cur_prefix = st[cur_slot].prefix;
+            }
+            if (cur_slot >= LGL_MAXL) continue;
+            const uint32_t key = f2key(depth[(size_t)y * W + x]);
+            if ((key & himask) != (cur_prefix & himask)) continue;
+            const int bin = (int)((key >> shift) & 0xFFu);
+            if (bin != cur_bin) {
+                if (cnt) atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt);
+                cnt = 0;
+                cur_bin = bin;
+            }
+            cnt++;
+        }
+        if (cnt) atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LGL_MAXL * 256; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// pick the bin holding the wanted rank, descend; one thread per slot
+__global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, int pass, int nslots_max) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots_max) return;
+    uint32_t* h = hist + s * 256;
+    uint32_t rank = st[s].rank, accum = 0;
+    int bin = 255;
+    for (int b = 0; b < 256; b++) {
+        uint32_t c = h[b];
+        if (rank < accum + c) { bin = b; break; }
+        accum += c;
+    }
+    uint32_t inbin = h[bin];
+    st[s].prefix |= ((uint32_t)bin) << (8 * pass);
+    st[s].rank = rank - accum;
+    if (pass == 0) {
+        st[s].key = st[s].prefix;
+        st[s].n_le = inbin - (rank - accum) - 1;  // elements equal to the key ranked ABOVE the selected one
+    }
+    for (int b = 0; b < 256; b++) h[b] = 0;  // ready for the next pass
+}
+
+// smallest key strictly greater than the selected key, per slot (upper median for even counts)
+__global__ __launch_bounds__(256) void k_successor(const int16_t* __restrict__ lab, const float* __restrict__ depth, int H,
+                                                   int W, const unsigned long long* __restrict__ pres,
+                                                   const int* __restrict__ pre, const SelState* __restrict__ st,
+                                                   uint32_t* __restrict__ succ) {
+    __shared__ uint32_t s_m[LGL_MAXL];
+    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) s_m[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int id = lab[i];
+        if (id <= 0) continue;
+        int s = slot_of(id, pres, pre);
+        if (s >= LGL_MAXL) continue;
+        uint32_t key = f2key(depth[i]);
+        if (key > st[s].key && key < s_m[s]) atomicMin(&s_m[s], key);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LGL_MAXL; i += 256)
+        if (s_m[i] != 0xFFFFFFFFu) atomicMin(&succ[i], s_m[i]);
+}
+
+// ---------------------------------------------------------------- exact EDT extrema
+// phase 1: g[y][x] = vertical distance to the nearest leaf pixel of column x (sentinel when none)
+#define LGL_GINF 16384
+__global__ __launch_bounds__(256) void k_coldist(const int16_t* __restrict__ lab, int H, int W, uint16_t* __restrict__ g) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    int d = LGL_GINF;
+#pragma unroll 8
+    for (int y = 0; y < H; y++) {
+        d = (lab[(size_t)y * W + x] >= 1) ? 0 : min(d + 1, LGL_GINF);
+        g[(size_t)y * W + x] = (uint16_t)d;
+    }
+    d = LGL_GINF;
+#pragma unroll 8
+    for (int y = H - 1; y >= 0; y--) {
+        int v = g[(size_t)y * W + x];
+        d = (v == 0) ? 0 : min(d + 1, LGL_GINF);
+        if (d < v) g[(size_t)y * W + x] = (uint16_t)d;
+    }
+}
+
+// phase 2: one wave per row.  D2(x) = min_x' (x-x')^2 + g(x')^2 ; the leftmost arg-min is monotone in x
+// (Monge), so positions are solved in bisection order, each searching only between its solved neighbours.
+template <int WP2>  // padded power-of-two width
+__global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, int H, int W,
+                                               unsigned long long* __restrict__ best) {
+    __shared__ int s_g2[WP2];
+    __shared__ int s_opt[WP2 + 1];
+    const int y = blockIdx.x, lane = threadIdx.x;
+    for (int x = lane; x < WP2; x += 64) {
+        int v = (x < W) ? (int)g[(size_t)y * W + x] : LGL_GINF;
+        s_g2[x] = v * v;
+    }
+    __syncthreads();
+    unsigned long long mykey = 0;
+    auto cost = [&](int x, int xp) { int d = x - xp; return d * d + s_g2[xp]; };
+    // level l solves positions p = (2i+1) * WP2 / 2^(l+1); neighbours p -/+ half are solved (or the borders)
+    for (int half = WP2 / 2; half >= 1; half >>= 1) {
+        const int nsub = WP2 / (2 * half);
+        if (nsub < 64) {
+            const int lanes_per = 64 / nsub;        // lanes cooperating on one position
+            const int sub = lane / lanes_per, li = lane % lanes_per;
+            const int p = (2 * sub + 1) * half;
+            const int lo = (p - half > 0) ? s_opt[p - half] : 0;
+            const int hi = (p + half < WP2) ? s_opt[p + half] : W - 1;
+            int bc = INT_MAX, bx = lo;
+            if (p < W)
+                for (int xp = lo + li; xp <= hi; xp += lanes_per) {
+                    int c = cost(p, xp);
+                    if (c < bc) { bc = c; bx = xp; }
+                }
+            for (int o = 1; o < lanes_per; o <<= 1) {   // leftmost arg-min across the cooperating lanes
+                int oc = __shfl_xor(bc, o, 64), ox = __shfl_xor(bx, o, 64);
+                if (oc < bc || (oc == bc && ox < bx)) { bc = oc; bx = ox; }
+            }
+            __syncthreads();
+            if (li == 0) {
+                s_opt[p] = (p < W) ? bx : W - 1;
+                if (p < W && bc > 0) {
+                    unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W + p));
+                    mykey = key > mykey ? key : mykey;
+                }
+            }
+            __syncthreads();
+        } else {
+            for (int sub = lane; sub < nsub; sub += 64) {
+                const int p = (2 * sub + 1) * half;
+                int res = W - 1;
+                if (p < W) {
+                    const int lo = (p - half > 0) ? s_opt[p - half] : 0;
+                    const int hi = (p + half < WP2) ? s_opt[p + half] : W - 1;
+                    int bc = INT_MAX, bx = lo;
+                    for (int xp = lo; xp <= hi; xp++) {
+                        int c = cost(p, xp);
+                        if (c < bc) { bc = c; bx = xp; }
+                    }
+                    res = bx;
+                    if (bc > 0) {
+                        unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W + p));
+                        mykey = key > mykey ? key : mykey;
+                    }
+                }
+                s_opt[p] = res;
+            }
+            __syncthreads();
+        }
+    }
+    // position 0 is never a bisection midpoint: solve it against [0, opt(1)]
+    if (lane == 0) {
+        const int hi = (WP2 > 1) ? s_opt[1] : W - 1;
+        int bc = INT_MAX;
+        for (int xp = 0; xp <= min(hi, W - 1); xp++) bc = min(bc, cost(0, xp));
+        if (bc > 0) {
+            unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W));
+            mykey = key > mykey ? key : mykey;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long w = __shfl_xor(mykey, o, 64);
+        mykey = w > mykey ? w : mykey;
+    }
+    if (lane == 0 && mykey) atomicMax(best, mykey);
+}
+
+}  // namespace
+
+struct LgLeafWs {
+    unsigned long long* pres;  // 512
+    int* pre;                  // 512
+    int* nlab;                 // 1
+    LeafAcc* acc;              // MAXL
+    unsigned long long* first_leaf;  // 1
+    SelState* st;              // MAXL
+    uint32_t* hist;            // MAXL*256
+    uint32_t* succ;            // MAXL
+    unsigned long long* best;  // 1
+    uint16_t* g;               // H*W
+    size_t g_cap;
+};
+
+void lg_leaf_free(LgLeafWs*& w) {
+    if (!w) return;
+    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g};
+    for (void* p : ps)
+        if (p) hipFree(p);
+    delete w;
+    w = nullptr;
+}
+
+static int leaf_ws(LgLeafWs*& w, int H, int W) {
+    if (!w) {
+        w = new LgLeafWs();
+        memset(w, 0, sizeof(*w));
+        if (hipMalloc((void**)&w->pres, 512 * 8) || hipMalloc((void**)&w->pre, 512 * 4) || hipMalloc((void**)&w->nlab, 4) ||
+            hipMalloc((void**)&w->acc, sizeof(LeafAcc) * LGL_MAXL) || hipMalloc((void**)&w->first_leaf, 8) ||
+            hipMalloc((void**)&w->st, sizeof(SelState) * LGL_MAXL) || hipMalloc((void**)&w->hist, 4 * LGL_MAXL * 256) ||
+            hipMalloc((void**)&w->succ, 4 * LGL_MAXL) || hipMalloc((void**)&w->best, 8))
+            return LG_ERR_NOMEM;
+    }
+    size_t need = (size_t)H * W;
+    if (need > w->g_cap) {
+        if (w->g) hipFree(w->g);
+        w->g = nullptr;
+        if (hipMalloc((void**)&w->g, need * 2)) return LG_ERR_NOMEM;
+        w->g_cap = need;
+    }
+    return LG_OK;
+}
+
+int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
+                lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, std::string* err) {
+    int rc = leaf_ws(w, H, W);
+    if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
+    const long long n = (long long)H * W;
+    const int grid = 1024;
+    hipMemsetAsync(w->pres, 0, 512 * 8, s);
+    hipMemsetAsync(w->acc, 0, sizeof(LeafAcc) * LGL_MAXL, s);
+    hipMemsetAsync(w->first_leaf, 0xFF, 8, s);
+    hipMemsetAsync(w->hist, 0, 4 * LGL_MAXL * 256, s);
+    hipMemsetAsync(w->succ, 0xFF, 4 * LGL_MAXL, s);
+    hipMemsetAsync(w->best, 0, 8, s);
+    hipLaunchKernelGGL(k_presence, dim3(grid), dim3(256), 0, s, labels, n, w->pres);
+    hipLaunchKernelGGL(k_prefix, dim3(1), dim3(64), 0, s, w->pres, w->pre, w->nlab);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc,
+                       w->first_leaf);
+    // clutter extrema (independent of the statistics)
+    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256), dim3(256), 0, s, labels, H, W, w->g);
+    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
+    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
+    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
+    else if (W <= 4096) hipLaunchKernelGGL(k_rowedt<4096>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
+    else { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
+    // need the areas on the host to seed the median ranks
+    int nlab = 0;
+    std::vector<LeafAcc> acc(LGL_MAXL);
+    std::vector<unsigned long long> pres(512);
+    if (hipMemcpyAsync(&nlab, w->nlab, 4, hipMemcpyDeviceToHost, s) || hipMemcpyAsync(acc.data(), w->acc, sizeof(LeafAcc) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(pres.data(), w->pres, 512 * 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s)) {
+        *err = "lg_leaf_stats: device copy failed";
+        return LG_ERR_HIP;
+    }
+    if (nlab > LGL_MAXL) { *err = "lg_leaf_stats: more than 64 distinct leaf labels in one frame"; return LG_ERR_UNSUPPORTED; }
+    if (nlab > max_leaves) { *err = "lg_leaf_stats: stats capacity too small"; return LG_ERR_INVALID; }
+    std::vector<SelState> st(LGL_MAXL);
+    for (int i = 0; i < LGL_MAXL; i++) {
+        st[i].prefix = 0; st[i].key = 0; st[i].n_le = 0;
+        st[i].rank = (i < nlab && acc[i].area) ? (uint32_t)((acc[i].area - 1) / 2) : 0;  // lower median index
+    }
+    hipMemcpyAsync(w->st, st.data(), sizeof(SelState) * LGL_MAXL, hipMemcpyHostToDevice, s);
+    if (nlab > 0) {
+        for (int pass = 3; pass >= 0; pass--) {
+            hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, pass, w->hist);
+            hipLaunchKernelGGL(k_select, dim3(1), dim3(LGL_MAXL), 0, s, w->st, w->hist, pass, LGL_MAXL);
+        }
+        hipLaunchKernelGGL(k_successor, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, w->succ);
+    }
+    std::vector<uint32_t> succ(LGL_MAXL);
+    unsigned long long first_leaf = 0, best = 0;
+    if (hipMemcpyAsync(st.data(), w->st, sizeof(SelState) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(succ.data(), w->succ, 4 * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(&first_leaf, w->first_leaf, 8, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(&best, w->best, 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s) || hipGetLastError()) {
+        *err = "lg_leaf_stats: device copy / kernel failed";
+        return LG_ERR_HIP;
+    }
+    // ids in ascending order = slots in ascending order
+    int slot = 0;
+    for (int wi = 0; wi < 512 && slot < nlab; wi++) {
+        unsigned long long bits = pres[wi];
+        while (bits && slot < nlab) {
+            int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            lg_leaf_stat& o = stats[slot];
+            memset(&o, 0, sizeof(o));
+            o.id = wi * 64 + b;
+            o.area = (int32_t)acc[slot].area;
+            o.touches_border = acc[slot].border;
+            o.sum_x = (double)acc[slot].sum_x;
+            o.sum_y = (double)acc[slot].sum_y;
+            o.sum_depth = acc[slot].sum_depth;
+            o.sum_ray = acc[slot].sum_ray;
+            // np.median: odd n -> middle element; even n -> float32 mean of the two middle elements
+            auto k2f = [](uint32_t k) { uint32_t bb = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float fv; memcpy(&fv, &bb, 4); return fv; };
+            float lo = k2f(st[slot].key);
+            if (acc[slot].area % 2 == 1) {
+                o.median_depth = lo;
+            } else {
+                float hi = (st[slot].n_le > 0) ? lo : k2f(succ[slot]);  // duplicates of the key cover the upper index
+                float sum = lo + hi;                                     // float32 add, then /2 (np.mean of 2 float32)
+                o.median_depth = sum / 2.0f;
+            }
+            slot++;
+        }
+    }
+    *n_leaves = nlab;
+    // extrema: argmin = first leaf pixel (row-major); argmax = farthest background pixel, first occurrence
+    if (first_leaf == ~0ull) { extrema[0] = 0; extrema[1] = 0; }
+    else { extrema[0] = (int32_t)(first_leaf / W); extrema[1] = (int32_t)(first_leaf % W); }
+    if (best == 0) { extrema[2] = 0; extrema[3] = 0; }  // no background pixel: the field is all zeros -> argmax index 0
+    else {
+        uint32_t idx = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+        extrema[2] = (int32_t)(idx / W); extrema[3] = (int32_t)(idx % W);
+    }
+    return LG_OK;
+}

@@ -1,0 +1,176 @@
+"""OptimalLeafSelector -- drop-in mirror of scripts/utils/leaf_scorer.py::OptimalLeafSelector.
+
+The L full-frame passes per leaf of the reference (boolean masks, fancy indexing, np.median, the global
+distance field) are replaced by lg_leaf_stats (include/leafgrasp.h): a fixed number of streaming HIP passes
+that return per-label area / centroid sums / depth sums / exact median depth / border flag and the two
+clutter extrema.  The remaining arithmetic is O(#leaves) and stays on the host in NumPy with the
+reference's dtypes (float32 medians and means, float64 scores).
+
+Semantics note (DESIGN.md "Clutter field"): the reference calls skfmm.distance (scikit-fmm 2022.3.26, not
+available) and only consumes the arg-extrema; this build defines the field as the exact Euclidean distance to
+the nearest leaf pixel (arg-max with first-occurrence ties).  PARITY UNPINNED vs scikit-fmm.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import LgLeafStat, check, lib
+from ._log import logerr, loginfo, logwarn
+from .grasp_point_selector import _device_index
+
+_VP = C.c_void_p
+_MAX_LEAVES = 64
+
+
+def pareto_mask_max(scores):
+    """paretoset(scores, sense=['max']*k): non-dominated rows, first of identical rows kept
+    (paretoset 1.2.3 is not installed; leaf_scorer.py:158,163)."""
+    s = np.asarray(scores, np.float64)
+    n = len(s)
+    keep = np.ones(n, bool)
+    for i in range(n):
+        for j in range(n):
+            if i != j and np.all(s[j] >= s[i]) and (np.any(s[j] > s[i]) or j < i):
+                keep[i] = False
+                break
+    return keep
+
+
+class OptimalLeafSelector:
+    def __init__(self, device):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.camera_cx = None  # leaf_scorer.py:14-17
+        self.camera_cy = None
+        self.f_norm = None
+        self._h = _VP()
+        check(None, lib.lg_create(_device_index(self.device), C.byref(self._h)), "lg_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                lib.lg_destroy(self._h)
+                self._h = _VP()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def set_camera_params(self, projection_matrix):  # :19-23
+        self.f_norm = projection_matrix[0, 0]
+        self.camera_cx = projection_matrix[0, 2]
+        self.camera_cy = projection_matrix[1, 2]
+
+    def get_tall_leaves(self):  # :205-207
+        return self._tall_leaves if hasattr(self, "_tall_leaves") else []
+
+    # ------------------------------------------------------------------ device pass
+    def leaf_statistics(self, mask_tensor, depth_tensor):
+        """-> (list of dict per label id ascending, (min_global (y,x), max_global (y,x)))."""
+        lab = torch.as_tensor(mask_tensor).to(self.device)
+        if lab.dtype != torch.int16:
+            lab = lab.to(torch.int16)  # wire dtype of /leaves_masks (leaf_grasp_node_v3.py:188)
+        lab = lab.contiguous()
+        dep = torch.as_tensor(depth_tensor).to(self.device, torch.float32).contiguous()
+        H, W = lab.shape
+        stats = (LgLeafStat * _MAX_LEAVES)()
+        n = C.c_int(0)
+        ext = (C.c_int32 * 4)()
+        with torch.cuda.device(self.device):
+            check(self._h, lib.lg_leaf_stats(self._h, lab.data_ptr(), dep.data_ptr(), H, W,
+                                             float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
+                                             stats, _MAX_LEAVES, C.byref(n), ext,
+                                             _VP(torch.cuda.current_stream(self.device).cuda_stream)), "lg_leaf_stats")
+        out = []
+        for i in range(n.value):
+            s = stats[i]
+            out.append(dict(id=int(s.id), area=int(s.area), touches_border=bool(s.touches_border),
+                            sum_x=float(s.sum_x), sum_y=float(s.sum_y), sum_depth=float(s.sum_depth),
+                            sum_ray=float(s.sum_ray), median_depth=np.float32(s.median_depth)))
+        return out, ((int(ext[0]), int(ext[1])), (int(ext[2]), int(ext[3]))), (H, W)
+
+    # ------------------------------------------------------------------ the selection (:25-203)
+    def select_optimal_leaf(self, mask_tensor, depth_tensor, return_debug=False):
+        """Enhanced leaf selection with tall leaf consideration."""
+        try:
+            stats, (min_global, max_global), (H, W) = self.leaf_statistics(mask_tensor, depth_tensor)
+            # torch.unique(mask)[1:] skips the smallest value (the background 0 when present, :32)
+            total = sum(s["area"] for s in stats)
+            if total == H * W and stats:
+                stats = stats[1:]
+            depth_list = [s["median_depth"] for s in stats if s["area"] > 0]
+            if not depth_list:
+                return None
+            depth_mean = np.mean(np.array(depth_list))  # float32, like the reference (:53-54)
+            tall_leaves = [s["id"] for s in stats if s["median_depth"] < depth_mean]  # :58-62
+            loginfo(f"Found {len(tall_leaves)} tall leaves (average depth: {depth_mean:.3f}m)")
+            candidates = []
+            for s in stats:
+                area = s["area"]
+                if area < 10000:  # :79-81
+                    continue
+                centroid = (s["sum_x"] / area, s["sum_y"] / area)  # :84-88
+                dist_to_min = np.sqrt((centroid[0] - min_global[1]) ** 2 + (centroid[1] - min_global[0]) ** 2)
+                dist_to_max = np.sqrt((centroid[0] - max_global[1]) ** 2 + (centroid[1] - max_global[0]) ** 2)
+                total_dist = dist_to_min + dist_to_max
+                clutter_score = dist_to_min / total_dist if total_dist > 0 else 0  # :91-101
+                mean_depth = np.float32(s["sum_depth"] / area)  # np.mean of float32 depths (:105-106)
+                # mean over pixels of sqrt(X^2+Y^2+Z^2) with X=(mean_depth*(x-cx))/f ... = mean_depth/f * mean ray (:109-115)
+                mean_distance = float(mean_depth) / float(self.f_norm) * (s["sum_ray"] / area)
+                distance_score = np.exp(-mean_distance / 0.3)  # :117
+                if s["touches_border"]:  # :277-306
+                    visibility_score = 0.0
+                else:
+                    d = np.sqrt((centroid[0] - W / 2) ** 2 + (centroid[1] - H / 2) ** 2)
+                    visibility_score = 1.0 - d / np.sqrt((W / 2) ** 2 + (H / 2) ** 2)
+                candidates.append({
+                    "leaf_id": s["id"],
+                    "scores": np.array([clutter_score, distance_score, visibility_score], dtype=np.float64),
+                    "raw_scores": {"clutter": clutter_score, "distance": mean_distance, "visibility": visibility_score},
+                    "is_tall": s["id"] in tall_leaves,
+                    "centroid": centroid,
+                })
+            if not candidates:
+                logwarn("No valid leaf candidates found")
+                return None
+            try:
+                tall_c = [c for c in candidates if c["is_tall"]]
+                reg_c = [c for c in candidates if not c["is_tall"]]
+                if tall_c:  # :150-160
+                    scores = np.stack([c["scores"] for c in tall_c]) * 1.1
+                    pm = pareto_mask_max(scores)
+                    pareto = [c for i, c in enumerate(tall_c) if pm[i]]
+                else:
+                    scores = np.stack([c["scores"] for c in reg_c])
+                    pm = pareto_mask_max(scores)
+                    pareto = [c for i, c in enumerate(reg_c) if pm[i]]
+                if not pareto:
+                    pareto = tall_c if tall_c else reg_c
+                weights = np.array([0.35, 0.35, 0.3])  # :170
+                best_score, best_leaf = float("-inf"), None
+                self._tall_leaves = tall_leaves
+                for c in pareto:
+                    ws = np.sum(weights * c["scores"])
+                    if ws > best_score:
+                        best_score, best_leaf = ws, c["leaf_id"]
+                if return_debug:
+                    return best_leaf, dict(candidates=candidates, tall=tall_leaves, extrema=(min_global, max_global),
+                                           depth_list=depth_list)
+                return best_leaf
+            except Exception as e:  # noqa: BLE001  (:198-202)
+                logerr(f"Error in Pareto optimization: {str(e)}")
+                if candidates:
+                    return max(candidates, key=lambda x: np.mean(x["scores"]))["leaf_id"]
+                return None
+        except Exception as e:  # noqa: BLE001  (:201-203)
+            logerr(f"Error in leaf selection: {str(e)}")
+            return None
+
+    def _calculate_visibility_score(self, leaf_mask):  # :277-306, host helper kept for callers
+        leaf_mask = np.asarray(leaf_mask.cpu() if torch.is_tensor(leaf_mask) else leaf_mask).astype(bool)
+        h, w = leaf_mask.shape
+        ys, xs = np.where(leaf_mask)
+        if len(ys) == 0:
+            return 0.0
+        if leaf_mask[0, :].sum() + leaf_mask[-1, :].sum() + leaf_mask[:, 0].sum() + leaf_mask[:, -1].sum() > 0:
+            return 0.0
+        d = np.sqrt((np.mean(xs) - w / 2) ** 2 + (np.mean(ys) - h / 2) ** 2)
+        return 1.0 - d / np.sqrt((w / 2) ** 2 + (h / 2) ** 2)
