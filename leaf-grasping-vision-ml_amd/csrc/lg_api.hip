@@ -2,6 +2,7 @@
 // the orientation hand-off, per-kernel event timing.  No exceptions cross the boundary.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -363,6 +364,7 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     gaussian1d(a.k1);
+    a.nt_stores = getenv("LG_NT_STORES") ? 1 : 0;  // measured: non-temporal plane stores are 1.6x SLOWER here (0.57 vs 0.35 ms)
     {
         ProfScope ps(h, "final", s);
         lg_launch_final(a, s);

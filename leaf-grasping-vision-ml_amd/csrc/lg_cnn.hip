@@ -25,7 +25,7 @@ constexpr LayerCfg kLayers[6] = {
 // WG = 256 threads = 4 waves; wave tile = 2 pixel-blocks x 2 channel-blocks (4 accumulators).
 // PP = pixel-block pairs per workgroup, CP = channel-block pairs per workgroup, PP*CP == 4.
 template <int CIN, int CINP, int COUT, int WI, bool POOL, int KC, int PP, int CP>
-__global__ __launch_bounds__(256) void lg_conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ out) {
     static_assert(PP * CP == 4, "4 waves per workgroup");
     constexpr int PBROWS = 32 / WI > 0 ? 32 / WI : 1;   // image rows per 32-pixel block (WI=32:1, 16:2, 8:4)
@@ -66,25 +66,57 @@ __global__ __launch_bounds__(256) void lg_conv3x3_kernel(const float* __restrict
     const int aoff = (wc_i * 64) + (lane & 31);           // A-operand: channel inside the tile (+32 for block 1)
 
     const float* in_n = in + (size_t)n * CIN * WI * WI;
-    for (int c0 = 0; c0 < CINP; c0 += KC) {
-        __syncthreads();
-        // ---- stage input chunk [KC][TR][TWID] with zero padding (conv padding=1)
-        for (int idx = t; idx < KC * TR * TWID; idx += 256) {
+    // Software pipeline: the global loads of chunk c+1 are issued into registers before the MFMA loop of
+    // chunk c and written to LDS after it, so HBM/L2 latency hides under the matrix work.
+    constexpr int IN_ELEMS = KC * TR * TWID;
+    constexpr int NIN = (IN_ELEMS + 255) / 256;
+    constexpr int W4_ELEMS = 9 * KC * (COUT_T / 4);
+    constexpr int NW4 = (W4_ELEMS + 255) / 256;
+    float rin[NIN];
+    float4 rw[NW4];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NIN; j++) {
+            const int idx = t + 256 * j;
             const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
             const int ry = r2 / TWID, rx = r2 % TWID;
             const int gy = y0 - 1 + ry, gx = rx - 1, gc = c0 + ci;
             float v = 0.0f;
-            if (gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI) v = in_n[((size_t)gc * WI + gy) * WI + gx];
-            s_in[ci * IN_CH_STRIDE + r2] = v;
+            if (idx < IN_ELEMS && gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI)
+                v = in_n[((size_t)gc * WI + gy) * WI + gx];
+            rin[j] = v;
         }
-        // ---- stage weight chunk [9][KC][COUT_T] from packed [9][CINP][COUT]
-        for (int idx = t; idx < 9 * KC * (COUT_T / 4); idx += 256) {
+#pragma unroll
+        for (int j = 0; j < NW4; j++) {
+            const int idx = t + 256 * j;
             const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
             const int ci = rest % KC, tap = rest / KC;
-            const float4 v = *reinterpret_cast<const float4*>(wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q);
-            *reinterpret_cast<float4*>(&s_w[(tap * KC + ci) * COUT_T + 4 * q]) = v;
+            rw[j] = (idx < W4_ELEMS)
+                        ? *reinterpret_cast<const float4*>(wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIN; j++) {
+            const int idx = t + 256 * j;
+            if (idx < IN_ELEMS) s_in[(idx / (TR * TWID)) * IN_CH_STRIDE + idx % (TR * TWID)] = rin[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NW4; j++) {
+            const int idx = t + 256 * j;
+            if (idx < W4_ELEMS) {
+                const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
+                *reinterpret_cast<float4*>(&s_w[rest * COUT_T + 4 * q]) = rw[j];  // rest = tap*KC + ci
+            }
+        }
+    };
+    load_chunk(0);
+    for (int c0 = 0; c0 < CINP; c0 += KC) {
+        __syncthreads();   // every wave finished reading the previous chunk
+        store_chunk();
         __syncthreads();
+        if (c0 + KC < CINP) load_chunk(c0 + KC);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap % 3;

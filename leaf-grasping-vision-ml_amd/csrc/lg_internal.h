@@ -50,6 +50,7 @@ struct LgFinalArgs {
     float min_edge_distance, stem_valid_thresh;
     float inv_maxd;
     float k1[5];  // separable 1-D Gaussian (size 5, sigma 5/6)
+    int nt_stores;  // 0: plain stores (default); 1: non-temporal plane stores (LG_NT_STORES=1; measured slower)
 };
 
 // kernel launchers (lg_kernels.hip)

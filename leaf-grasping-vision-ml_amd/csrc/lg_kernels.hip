@@ -30,6 +30,10 @@ __device__ __forceinline__ int lg_wave_shr1(int old, int v) {  // lane i <- lane
 __device__ __forceinline__ int lg_wave_shl1(int old, int v) {  // lane i <- lane i+1 (lane 63 keeps old)
     return __builtin_amdgcn_update_dpp(old, v, 0x130, 0xf, 0xf, false);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), which would stall
+// every image row of the distance-transform sweeps on its own global prefetch (rows are ~1000 cycles apart,
+// HBM latency is longer): LDS operations are complete at lgkmcnt(0), global loads/stores stay in flight.
+__device__ __forceinline__ void lg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ unsigned long long lg_wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -158,7 +162,7 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
 // All arithmetic is exact 16.16 integers, so any evaluation order gives OpenCV's integers.
 // grid = (2, B): blockIdx.x selects d_in (src = mask) or d_out (src = !mask).
 // The backward sweep is the same code on the 180-degree-rotated image.
-template <int T, int E, bool BWD>
+template <int T, int E, bool BWD, bool VEC>
 __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ tmp,
                                                    float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
                                                    int W) {
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     uint32_t* tp = tmp + ((size_t)frame * 2 + which) * H * W;
     float* dout = (dist_out && which == 0) ? dist_out + fo : nullptr;  // only d_in is a contract plane
     const int pc0 = BWD ? WP - (t + 1) * E : t * E;  // first physical column of this thread (multiple of E)
-    const bool vec_ok = (W % E) == 0;
+    constexpr bool vec_ok = VEC;  // host guarantees W % E == 0 when VEC
     const bool full = vec_ok && (pc0 + E <= W);
     const int c0 = t * E;  // first logical column
 
@@ -189,37 +193,46 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     constexpr int RAWN = BWD ? E : (E + 3) / 4;
     uint32_t raw[D][RAWN];
 
+    // Branch-free prefetch: addresses are clamped into the image and out-of-image lanes are fixed up by
+    // selects, so the compiler keeps the loads in flight (a load inside a divergent branch is waited for
+    // with vmcnt(0) at the join, which serialises every image row on HBM latency).
+    const int pc0c = full ? pc0 : (vec_ok ? max(0, min(pc0, W - E)) : 0);
     auto load_row = [&](int r, uint32_t* dst) {  // r = logical row
-        const int prow = BWD ? H - 1 - r : r;
-        if (r >= H) return;
-        if (BWD) {
-            const uint32_t* src = tp + (size_t)prow * W + pc0;
-            if (full) {
+        const int rr = min(r, H - 1);
+        const int prow = BWD ? H - 1 - rr : rr;
+        if (vec_ok) {   // raw values only; out-of-image lanes are fixed up at the point of use
+            if (BWD) {
+                const uint32_t* src = tp + (size_t)prow * W + pc0c;
 #pragma unroll
                 for (int q = 0; q < E / 4; q++) {
                     uint4 v = *reinterpret_cast<const uint4*>(src + 4 * q);
                     dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
                 }
             } else {
-#pragma unroll
-                for (int k = 0; k < E; k++) dst[k] = (pc0 + k < W) ? src[k] : LG_INF;
-            }
-        } else {
-            const uint8_t* src = m + (size_t)prow * W + pc0;
-            if (full) {
+                const uint8_t* src = m + (size_t)prow * W + pc0c;
                 if (E == 4) {
                     dst[0] = *reinterpret_cast<const uint32_t*>(src);
                 } else {
                     uint2 v = *reinterpret_cast<const uint2*>(src);
                     dst[0] = v.x; dst[1] = v.y;
                 }
+            }
+        } else {  // generic width: scalar, still branch-free
+            if (BWD) {
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    const int pc = min(pc0 + k, W - 1);
+                    uint32_t v = tp[(size_t)prow * W + pc];
+                    dst[k] = (pc0 + k < W) ? v : LG_INF;
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < RAWN; q++) dst[q] = 0;
 #pragma unroll
                 for (int k = 0; k < E; k++) {
-                    // out-of-image columns behave as ordinary non-source pixels: encode as "src nonzero"
-                    uint32_t mb = (pc0 + k < W) ? (uint32_t)src[k] : (which ? 0u : 1u);
+                    const int pc = min(pc0 + k, W - 1);
+                    uint32_t mb = m[(size_t)prow * W + pc];
+                    mb = (pc0 + k < W) ? mb : (which ? 0u : 1u);
                     dst[k >> 2] |= (mb & 0xffu) << (8 * (k & 3));
                 }
             }
@@ -241,10 +254,11 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 #pragma unroll
                 for (int k = 0; k < E; k++) {
                     if (BWD) {
-                        init[k] = raw[d][E - 1 - k];
+                        init[k] = (vec_ok && !full) ? LG_INF : raw[d][E - 1 - k];
                     } else {
                         uint32_t mb = (raw[d][k >> 2] >> (8 * (k & 3))) & 0xffu;
                         bool nz = which ? (mb == 0) : (mb != 0);
+                        if (vec_ok && !full) nz = true;  // out-of-image columns: ordinary non-source pixels
                         init[k] = nz ? 0xFFFFFFFFu : 0u;
                     }
                 }
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                 int pin = lg_wave_prefix_min(mloc);
                 if (lane == 63) s_wtot[par][wave] = pin;
                 int excl = lg_wave_shr1(INT_MAX, pin);
-                __syncthreads();
+                lg_lds_barrier();
 #pragma unroll
                 for (int w = 0; w < NW - 1; w++)
                     if (w < wave) excl = min(excl, s_wtot[par][w]);
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                 uint32_t l1 = (uint32_t)lg_wave_shr1((int)LG_INF, (int)v[E - 1]);
                 uint32_t r0 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[0]);
                 uint32_t r1 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[1]);
-                __syncthreads();
+                lg_lds_barrier();
                 if (lane == 0 && wave > 0) { l0 = s_halo[par][wave - 1][2]; l1 = s_halo[par][wave - 1][3]; }
                 if (lane == 63 && wave < NW - 1) { r0 = s_halo[par][wave + 1][0]; r1 = s_halo[par][wave + 1][1]; }
                 p1[0] = l0; p1[1] = l1;
@@ -346,10 +360,14 @@ template <int T, int E>
 static void lg_dt_launch_t(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B,
                            int H, int W, hipStream_t s) {
     dim3 grid(2, B), block(T);
-    if (bwd)
-        hipLaunchKernelGGL((lg_dt5_kernel<T, E, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
-    else
-        hipLaunchKernelGGL((lg_dt5_kernel<T, E, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+    const bool vec = (W % E) == 0 && W >= E;
+    if (bwd) {
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+    } else {
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+    }
 }
 
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     constexpr int GH = LG_TH + 2;
     __shared__ __attribute__((aligned(16))) float s_dm[DH * DW];
     __shared__ float s_h[DH * GW];
-    __shared__ float s_g[GH * (GW + 2)];
+    float* const s_g = s_dm;  // the smoothed tile reuses the depth tile's LDS (dead after the horizontal pass)
+    static_assert(GH * (GW + 2) <= DH * DW, "g tile must fit in the depth tile");
     __shared__ unsigned long long s_key[4];
 
     // XCD-aware remap: each XCD (blockIdx % 8 group) walks a contiguous range of tiles
@@ -397,6 +416,33 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const size_t fo = (size_t)frame * H * W;
     const float* depth = a.depth + fo;
     const unsigned long long* bits = a.bits + (size_t)frame * H * WW;
+
+    // ---- issue the per-pixel operands first so their HBM latency overlaps the stencil phases
+    const int txi = t & 15, tyi = t >> 4;
+    const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
+    const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
+    float din_pre[2][4];
+    unsigned mnib_pre[2], snib_pre[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
+        mnib_pre[rr] = snib_pre[rr] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) din_pre[rr][j] = 0.0f;
+        if (y < H && x0 < W) {
+            const unsigned sh = (unsigned)(x0 & 63);
+            mnib_pre[rr] = (unsigned)(bits[(size_t)y * WW + bx] >> sh) & 0xfu;
+            snib_pre[rr] = (unsigned)(stemb[(size_t)y * WW + bx] >> sh) & 0xfu;
+            const float* dsrc = a.maps[LG_MAP_DISTANCE] + fo + (size_t)y * W + x0;
+            if (vec) {
+                float4 v = *reinterpret_cast<const float4*>(dsrc);
+                din_pre[rr][0] = v.x; din_pre[rr][1] = v.y; din_pre[rr][2] = v.z; din_pre[rr][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) din_pre[rr][j] = (x0 + j < W) ? dsrc[j] : 0.0f;
+            }
+        }
+    }
 
     // ---- stage dm = depth * mask over the extended tile (reflect padding of smooth_depth, image_processor.py:60)
     const bool fast = ((W & 3) == 0) && (tx0 >= 4) && (tx0 + LG_TW + 4 <= W);
@@ -449,7 +495,6 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     __syncthreads();
 
     // ---- per-pixel planes
-    const int txi = t & 15, tyi = t >> 4;
     const LgFrameParams fp = a.fp[frame];
     const uint32_t mfi = a.maxfix[frame * 2 + 0], mfo = a.maxfix[frame * 2 + 1];
     const float maxabs = fmaxf((float)mfi * (1.0f / 65536.0f), (float)mfo * (1.0f / 65536.0f));
@@ -457,7 +502,6 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const float inv_2s2 = __frcp_rn(2.0f * a.optimal_distance * a.optimal_distance);
     const float f2 = a.f * a.f;
     const float ramp_step = (H > 1) ? (a.iso_ramp_bottom - a.iso_ramp_top) / (float)(H - 1) : 0.0f;
-    const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
     unsigned long long best = 0;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
@@ -465,25 +509,21 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
         const int y = ty0 + ly;
         const int x0 = tx0 + 4 * txi;
         if (y < H && x0 < W) {
-            const unsigned sh = (unsigned)(x0 & 63);
-            const unsigned mnib = (unsigned)(bits[(size_t)y * WW + bx] >> sh) & 0xfu;
-            const unsigned snib = (unsigned)(stemb[(size_t)y * WW + bx] >> sh) & 0xfu;
-            const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
-            float din[4];
-            const float* dsrc = a.maps[LG_MAP_DISTANCE] + fo + (size_t)y * W + x0;
-            if (vec) {
-                float4 v = *reinterpret_cast<const float4*>(dsrc);
-                din[0] = v.x; din[1] = v.y; din[2] = v.z; din[3] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) din[j] = (x0 + j < W) ? dsrc[j] : 0.0f;
-            }
+            const unsigned mnib = mnib_pre[rr], snib = snib_pre[rr];
+            const float* din = din_pre[rr];
             const float* g0 = &s_g[(ly + 0) * (GW + 2) + 4 * txi];
             const float* g1 = g0 + (GW + 2);
             const float* g2 = g1 + (GW + 2);
             float ga[6], gb[6], gc[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) { ga[j] = g0[j]; gb[j] = g1[j]; gc[j] = g2[j]; }
+            {   // 16-byte + 8-byte LDS reads (row stride 272 B keeps them aligned): no bank conflicts
+                const float4 a4 = *reinterpret_cast<const float4*>(g0), b4 = *reinterpret_cast<const float4*>(g1),
+                             c4 = *reinterpret_cast<const float4*>(g2);
+                const float2 a2 = *reinterpret_cast<const float2*>(g0 + 4), b2 = *reinterpret_cast<const float2*>(g1 + 4),
+                             c2 = *reinterpret_cast<const float2*>(g2 + 4);
+                ga[0] = a4.x; ga[1] = a4.y; ga[2] = a4.z; ga[3] = a4.w; ga[4] = a2.x; ga[5] = a2.y;
+                gb[0] = b4.x; gb[1] = b4.y; gb[2] = b4.z; gb[3] = b4.w; gb[4] = b2.x; gb[5] = b2.y;
+                gc[0] = c4.x; gc[1] = c4.y; gc[2] = c4.z; gc[3] = c4.w; gc[4] = c2.x; gc[5] = c2.y;
+            }
             const float dyp = (float)y - a.cy;
             const int dyb = min(y + 1, H - y);
             const float ramp = a.iso_ramp_top + ramp_step * (float)y;
@@ -497,7 +537,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
                 // flatness: Sobel cross-correlation on the smoothed plane, exp(-5 |grad|)   (:646-655)
                 float sx = (ga[j + 2] - ga[j]) + 2.0f * (gb[j + 2] - gb[j]) + (gc[j + 2] - gc[j]);
                 float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
-                float flat = __expf(-a.flat_scale * sqrtf(sx * sx + sy * sy));
+                float flat = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(sx * sx + sy * sy));  // v_sqrt_f32, 1 ulp
                 // closed-form geometry planes                                           (:502-524, :569-593)
                 const float dxp = (float)x - a.cx;
                 const float r2 = dxp * dxp + dyp * dyp;
@@ -534,7 +574,10 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
                 float* dst = a.maps[mi];
                 if (!dst) return;
                 if (vec) {
-                    *reinterpret_cast<float4*>(dst + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    typedef float lg_f4 __attribute__((ext_vector_type(4)));
+                    lg_f4 pk = {v[0], v[1], v[2], v[3]};
+                    if (a.nt_stores) __builtin_nontemporal_store(pk, reinterpret_cast<lg_f4*>(dst + off));  // write-once stream
+                    else *reinterpret_cast<lg_f4*>(dst + off) = pk;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -550,7 +593,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
             st4(LG_MAP_TRADITIONAL, o_trad);
             if (a.valid) {
                 if (vec) {
-                    *reinterpret_cast<uint32_t*>(a.valid + off) = vbytes;
+                    __builtin_nontemporal_store(vbytes, reinterpret_cast<uint32_t*>(a.valid + off));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
