@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for the cpu_baseline leg (0 = skip)")
@@ -166,9 +166,18 @@ def main():
         }
         if "final" in kern:
             achieved = FINAL_BYTES_PER_PX * px / (kern["final"]["avg_ms"] * 1e-3) / 1e9
+            # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
+            # + WRITE_SIZE), recorded per pixel in profiles/ by tools/pmc_final.sh; scaled to this launch.
+            traffic = None
+            try:
+                with open(os.path.join(REPO, "profiles", "r01_pmc_counters.json")) as fpmc:
+                    traffic = round(json.load(fpmc)["lg_final_kernel_summary"]["traffic_bytes_per_px"] * px)
+            except Exception:  # noqa: BLE001
+                traffic = None
             out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": None, "bytes_per_px": FINAL_BYTES_PER_PX}
+                               "traffic": traffic, "bytes_per_launch": round(FINAL_BYTES_PER_PX * px),
+                               "bytes_per_px": FINAL_BYTES_PER_PX}
         if "cnn" in kern and not args.no_cnn:
             fl = 312.83e6 * 20 * B
             tf = fl / (kern["cnn"]["avg_ms"] * 1e-3) / 1e12

@@ -79,7 +79,49 @@ __global__ __launch_bounds__(256) void lg_pack_bits_kernel(const uint8_t* __rest
     }
 }
 
+// Vector variant (W % 16 == 0): each lane loads 16 mask bytes (1 KiB per wave instruction), four adjacent
+// lanes assemble one 64-bit word.  Slot s of a row covers pixels [16s, 16s+16); slots beyond W are empty.
+__global__ __launch_bounds__(256) void lg_pack_bits16_kernel(const uint8_t* __restrict__ mask,
+                                                             unsigned long long* __restrict__ bits, int W, int WW,
+                                                             long long nslots_total) {
+    const int slots_per_row = 4 * WW;
+    long long sid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;  // multiple of 4: a word's four slots stay in adjacent lanes
+    for (; sid < nslots_total; sid += stride) {
+        const long long row = sid / slots_per_row;
+        const int slot = (int)(sid - row * slots_per_row);
+        const int x = slot * 16;
+        unsigned b16 = 0;
+        if (x < W) {
+            const uint4 v = *reinterpret_cast<const uint4*>(mask + row * W + x);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                b16 |= ((w4[q] & 0x000000ffu) ? 1u : 0u) << (4 * q);
+                b16 |= ((w4[q] & 0x0000ff00u) ? 2u : 0u) << (4 * q);
+                b16 |= ((w4[q] & 0x00ff0000u) ? 4u : 0u) << (4 * q);
+                b16 |= ((w4[q] & 0xff000000u) ? 8u : 0u) << (4 * q);
+            }
+        }
+        unsigned long long word = (unsigned long long)b16 << (16 * (slot & 3));
+        word |= __shfl_xor(word, 1, 64);
+        word |= __shfl_xor(word, 2, 64);
+        if ((slot & 3) == 0) bits[row * WW + (slot >> 2)] = word;
+    }
+}
+
 void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s) {
+    if ((W & 15) == 0 && ((uintptr_t)mask & 15) == 0) {
+        long long nslots = (long long)B * H * WW * 4;
+        long long blocks = (nslots + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        // all lanes of a wave must run the same number of iterations (shuffles): pad the slot space
+        long long per_iter = blocks * 256;
+        long long padded = ((nslots + per_iter - 1) / per_iter) * per_iter;
+        (void)padded;
+        hipLaunchKernelGGL(lg_pack_bits16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, mask, bits, W, WW, nslots);
+        return;
+    }
     long long nwords = (long long)B * H * WW;
     long long waves = nwords;
     int blocks = (int)((waves + 3) / 4);
