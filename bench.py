@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cnn", action="store_true", help="CV-only (diagnostic; NOT the headline config)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU (each on its own handle, stream and host thread); >1 lets the "
+                         "latency-bound sweeps of one batch run beside the CNN of another")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,11 +106,17 @@ def main():
     masks_np, depths_np, P = make_frames(B, H, W)
     masks = torch.from_numpy(masks_np).to(dev)
     depths = torch.from_numpy(depths_np).to(dev)
-    sel = L.GraspPointSelector(dev, load_model=False)
-    sel.set_camera_params(P)
+    import threading
+
     params = O.cnn_closed_form_params(seed=0)
-    if not args.no_cnn:
-        sel.set_cnn_state_dict(params)
+    sels = []
+    for _ in range(max(1, args.inflight)):
+        sel = L.GraspPointSelector(dev, load_model=False)
+        sel.set_camera_params(P)
+        if not args.no_cnn:
+            sel.set_cnn_state_dict(params)
+        sels.append(sel)
+    streams = [torch.cuda.Stream(dev) for _ in sels]
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -115,30 +124,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    lib.lg_profile_enable(sel._h, 1)
-    for _ in range(args.warmup):
-        sel.select_grasp_points_batch(masks, depths)
-    lib.lg_profile_enable(sel._h, 1)  # reset counters, keep the event pool
+    last = [None] * len(sels)
+
+    def run_steps(n_steps):
+        """n_steps passes over the batch; with --inflight N they are dealt round-robin to N host threads."""
+        def worker(i):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                for _ in range(i, n_steps, len(sels)):
+                    last[i] = sels[i].select_grasp_points_batch(masks, depths)
+        if len(sels) == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(len(sels))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+    for sel in sels:
+        lib.lg_profile_enable(sel._h, 1)
+    run_steps(max(args.warmup, len(sels)) if args.warmup else 0)
+    for sel in sels:
+        lib.lg_profile_enable(sel._h, 1)  # reset counters, keep the event pool
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = sel.select_grasp_points_batch(masks, depths)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    res = [r for r in last if r is not None][0]
     assert all(r[0] is not None for r in res), "synthetic frames must yield a grasp point"
 
     # per-kernel device time (HIP events recorded on the launch stream inside the library)
     kern = {}
     for name in ("prep", "stem", "dt_fwd", "dt_bwd", "final", "topk", "gather", "cnn"):
-        n, ms = C.c_int(0), C.c_double(0.0)
-        lib.lg_profile_read(sel._h, name.encode(), C.byref(n), C.byref(ms))
-        if n.value:
-            kern[name] = {"launches": n.value, "avg_ms": ms.value / n.value}
-    lib.lg_profile_enable(sel._h, 0)
+        tot_n, tot_ms = 0, 0.0
+        for sel in sels:
+            n, ms = C.c_int(0), C.c_double(0.0)
+            lib.lg_profile_read(sel._h, name.encode(), C.byref(n), C.byref(ms))
+            tot_n += n.value
+            tot_ms += ms.value
+        if tot_n:
+            kern[name] = {"launches": tot_n, "avg_ms": tot_ms / tot_n}
+    for sel in sels:
+        lib.lg_profile_enable(sel._h, 0)
 
     if rank == 0:
         frames = world * B * args.steps
@@ -159,7 +192,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{H}x{W} depth+mask, 8 score planes + valid + top-20 NMS + "
                                    f"{'CV only' if args.no_cnn else 'GraspPointCNN fp32 rescoring of 20 candidates'}",
-                       "frames_per_step_per_gpu": B, "height": H, "width": W,
+                       "frames_per_step_per_gpu": B, "height": H, "width": W, "batches_in_flight": len(sels),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "path_hbm_frac": round(fps / world * PATH_BYTES_PER_PX * H * W / (HBM_PEAK_GBS * 1e9), 5),
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},

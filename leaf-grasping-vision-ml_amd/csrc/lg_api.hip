@@ -30,6 +30,10 @@ struct lg_ctx {
     std::string err;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_prep = nullptr, ev_copy = nullptr;
+    // sub-batch pipeline of lg_select_grasp: latency-bound stages run beside the bandwidth / MFMA bound ones
+    hipStream_t s_dt[2] = {nullptr, nullptr}, s_main = nullptr, s_topk = nullptr;
+    std::vector<hipEvent_t> ev_pool;  // untimed events, 6 per sub-batch
+    hipEvent_t ev_begin = nullptr;
     // workspace, sized for (capB, capH, capW)
     int capB = 0, capH = 0, capW = 0, capK = 0;
     uint32_t* tmp = nullptr;
@@ -76,7 +80,9 @@ struct ProfScope {  // records an event pair around a launch when profiling is o
     hipStream_t s;
     LgProfSlot* slot = nullptr;
     hipEvent_t e1 = nullptr;
-    ProfScope(lg_ctx* h_, const char* name, hipStream_t s_) : h(h_), s(s_) {
+    hipEvent_t e0 = nullptr;
+    bool ext = false;  // true: the launch itself stamps e0/e1 (hipExtLaunchKernelGGL), nothing is recorded here
+    ProfScope(lg_ctx* h_, const char* name, hipStream_t s_, bool ext_ = false) : h(h_), s(s_), ext(ext_) {
         if (!h->prof_on) return;
         for (auto& p : h->prof)
             if (p.name == name) slot = &p;
@@ -91,12 +97,13 @@ struct ProfScope {  // records an event pair around a launch when profiling is o
             slot->ev.push_back(a);
             slot->ev.push_back(b);
         }
-        hipEventRecord(slot->ev[slot->used], s);
+        e0 = slot->ev[slot->used];
+        if (!ext) hipEventRecord(e0, s);
         e1 = slot->ev[slot->used + 1];
         slot->used += 2;
     }
     ~ProfScope() {
-        if (slot && e1) hipEventRecord(e1, s);
+        if (slot && e1 && !ext) hipEventRecord(e1, s);
     }
 };
 
@@ -224,6 +231,14 @@ int lg_create(int device, lg_handle* out) {
         delete h;
         return LG_ERR_HIP;
     }
+    if (hipStreamCreateWithFlags(&h->s_dt[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->s_dt[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->s_topk, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return LG_ERR_HIP;
+    }
     unsigned hw = std::thread::hardware_concurrency();
     h->host_threads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
     *out = h;
@@ -239,6 +254,10 @@ int lg_destroy(lg_handle h) {
     lg_leaf_free(h->leaf);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    if (h->ev_begin) hipEventDestroy(h->ev_begin);
+    for (hipStream_t q : {h->s_dt[0], h->s_dt[1], h->s_main, h->s_topk})
+        if (q) hipStreamDestroy(q);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
     if (h->ev_copy) hipEventDestroy(h->ev_copy);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
@@ -271,83 +290,90 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
     return LG_OK;
 }
 
-int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
-                  float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, float* theta_host, void* stream_) {
-    if (!h) return LG_ERR_INVALID;
-    if (!depth || !mask || B <= 0 || H < 8 || W < 8 || W > 8192 || H > 16384)
-        return fail(h, LG_ERR_INVALID, "lg_score_maps: bad pointer or shape (need H,W >= 8, W <= 8192)");
+}  // extern "C"
+
+namespace {
+
+struct Plan {  // one call's geometry, parameters and plane pointers (absolute, frame 0)
+    int B, H, W, WW, tiles_x, tiles_y;
     lg_params P;
-    if (pin) P = *pin; else lg_default_params(&P);
-    if (P.stem_se < 1 || P.stem_se > 64 || P.stem_bottom_div < 1)
-        return fail(h, LG_ERR_INVALID, "lg_score_maps: stem_se must be in [1,64], stem_bottom_div >= 1");
-    hipStream_t s = (hipStream_t)stream_;
-    LG_HIP(h, hipSetDevice(h->device));
-    int rc = ensure_ws(h, B, H, W, P.top_k);
-    if (rc) return rc;
-    const int WW = (W + 63) / 64;
-    const int tiles_x = (W + LG_TW - 1) / LG_TW, tiles_y = (H + LG_TH - 1) / LG_TH;
-    if (tiles_x * tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "lg_score_maps: image too large for the top-k tile table");
-
+    const float* depth;
+    const uint8_t* mask;
     float* maps[LG_NUM_MAPS];
-    for (int i = 0; i < LG_NUM_MAPS; i++) maps[i] = out_maps ? out_maps[i] : nullptr;
-    for (int i : {LG_MAP_DISTANCE, LG_MAP_TRADITIONAL})
-        if (!maps[i]) {
-            rc = ensure_ws_map(h, i);
-            if (rc) return rc;
-            maps[i] = h->ws_maps[i];
-        }
+    uint8_t* valid;
+};
 
-    LG_HIP(h, hipMemsetAsync(h->maxfix, 0, sizeof(uint32_t) * 2 * B, s));
+// pack bits + D2H of the bit rows on the copy stream
+int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_t ev_prep, hipEvent_t ev_copy) {
+    const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
+    LG_HIP(h, hipMemsetAsync(h->maxfix + 2 * (size_t)off, 0, sizeof(uint32_t) * 2 * n, s));
     {
         ProfScope ps(h, "prep", s);
-        lg_launch_pack_bits(mask, h->bits, B, H, W, WW, s);
+        lg_launch_pack_bits(pl.mask + off * px, h->bits + off * words, n, pl.H, pl.W, pl.WW, s);
     }
-    LG_HIP(h, hipEventRecord(h->ev_prep, s));
-    LG_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_prep, 0));
-    LG_HIP(h, hipMemcpyAsync(h->bits_host, h->bits, sizeof(unsigned long long) * (size_t)B * H * WW, hipMemcpyDeviceToHost,
-                             h->copy_stream));
-    LG_HIP(h, hipEventRecord(h->ev_copy, h->copy_stream));
+    LG_HIP(h, hipEventRecord(ev_prep, s));
+    LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
+    LG_HIP(h, hipMemcpyAsync(h->bits_host + off * words, h->bits + off * words, sizeof(unsigned long long) * n * words,
+                             hipMemcpyDeviceToHost, h->copy_stream));
+    LG_HIP(h, hipEventRecord(ev_copy, h->copy_stream));
+    return LG_OK;
+}
+
+// stem bits, forward + backward distance sweeps
+int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
+    const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
     {
         LgSeSpans se;
-        lg_make_se_spans(P.stem_se, &se);
+        lg_make_se_spans(pl.P.stem_se, &se);
         ProfScope ps(h, "stem", s);
-        lg_launch_stem_bits(h->bits, h->stem, B, H, W, WW, H - H / P.stem_bottom_div, se, s);
+        lg_launch_stem_bits(h->bits + off * words, h->stem + off * words, n, pl.H, pl.W, pl.WW,
+                            pl.H - pl.H / pl.P.stem_bottom_div, se, s);
     }
     {
         ProfScope ps(h, "dt_fwd", s);
-        if (lg_launch_dt(false, mask, h->tmp, nullptr, h->maxfix, B, H, W, s)) return fail(h, LG_ERR_UNSUPPORTED, "dt: width");
+        if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, s))
+            return fail(h, LG_ERR_UNSUPPORTED, "dt: width");
     }
     {
         ProfScope ps(h, "dt_bwd", s);
-        lg_launch_dt(true, mask, h->tmp, maps[LG_MAP_DISTANCE], h->maxfix, B, H, W, s);
+        lg_launch_dt(true, pl.mask + off * px, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
+                     h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, s);
     }
-    // ---- orientation hand-off: host contour analysis overlaps the distance-transform sweeps
-    LG_HIP(h, hipEventSynchronize(h->ev_copy));
-    {
-        const unsigned long long* hb = h->bits_host;
-        LgFrameParams* fph = h->fp_host;
-        parallel_for(B, h->host_threads, [=](int b) {
-            double o[5];
-            int ok = lg_host_orientation(hb + (size_t)b * H * WW, H, W, WW, o);
-            LgFrameParams f;
-            f.has_angle = ok;
-            f.theta = ok ? (float)o[0] : NAN;
-            f.sin_t = ok ? (float)sin(o[0]) : 0.f;
-            f.cos_t = ok ? (float)cos(o[0]) : 0.f;
-            fph[b] = f;
-        });
-        if (theta_host)
-            for (int b = 0; b < B; b++) theta_host[b] = fph[b].theta;
-    }
-    LG_HIP(h, hipMemcpyAsync(h->fp_dev, h->fp_host, sizeof(LgFrameParams) * B, hipMemcpyHostToDevice, s));
+    return LG_OK;
+}
 
+// host contour analysis of frames [off, off+n) (the bit rows must have landed: ev_copy synchronised)
+void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
+    const unsigned long long* hb = h->bits_host;
+    LgFrameParams* fph = h->fp_host;
+    const int H = pl.H, W = pl.W, WW = pl.WW;
+    parallel_for(n, h->host_threads, [=](int i) {
+        const int b = off + i;
+        double o[5];
+        int ok = lg_host_orientation(hb + (size_t)b * H * WW, H, W, WW, o);
+        LgFrameParams f;
+        f.has_angle = ok;
+        f.theta = ok ? (float)o[0] : NAN;
+        f.sin_t = ok ? (float)sin(o[0]) : 0.f;
+        f.cos_t = ok ? (float)cos(o[0]) : 0.f;
+        fph[b] = f;
+    });
+}
+
+// frame scalars H2D + the fused score-plane kernel
+int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
+    const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
+    const int H = pl.H, W = pl.W;
+    const lg_params& P = pl.P;
+    LG_HIP(h, hipMemcpyAsync(h->fp_dev + off, h->fp_host + off, sizeof(LgFrameParams) * n, hipMemcpyHostToDevice, s));
     LgFinalArgs a;
     memset(&a, 0, sizeof(a));
-    a.depth = depth; a.bits = h->bits; a.stem_bits = h->stem; a.maxfix = h->maxfix; a.fp = h->fp_dev;
-    for (int i = 0; i < LG_NUM_MAPS; i++) a.maps[i] = maps[i];
-    a.valid = out_valid ? out_valid : h->ws_valid;
-    a.tilekeys = h->tilekeys;
-    a.B = B; a.H = H; a.W = W; a.WW = WW; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+    a.depth = pl.depth + off * px; a.bits = h->bits + off * words; a.stem_bits = h->stem + off * words;
+    a.maxfix = h->maxfix + 2 * (size_t)off; a.fp = h->fp_dev + off;
+    for (int i = 0; i < LG_NUM_MAPS; i++) a.maps[i] = pl.maps[i] ? pl.maps[i] + off * px : nullptr;
+    a.valid = pl.valid ? pl.valid + off * px : nullptr;
+    a.tilekeys = h->tilekeys + (size_t)off * pl.tiles_x * pl.tiles_y;
+    a.B = n; a.H = H; a.W = W; a.WW = pl.WW; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
     a.cx = P.cx; a.cy = P.cy; a.f = P.f;
     a.w_approach = P.w_approach; a.w_sdf = P.w_sdf; a.w_flat = P.w_flat; a.w_access = P.w_access;
     a.sdf_w_interior = P.sdf_w_interior; a.sdf_w_align = P.sdf_w_align; a.sdf_w_sdf = P.sdf_w_sdf;
@@ -364,11 +390,62 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     gaussian1d(a.k1);
-    a.nt_stores = getenv("LG_NT_STORES") ? 1 : 0;  // measured: non-temporal plane stores are 1.6x SLOWER here (0.57 vs 0.35 ms)
+    a.nt_stores = getenv("LG_NT_STORES") ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
-        ProfScope ps(h, "final", s);
-        lg_launch_final(a, s);
+        ProfScope ps(h, "final", s, true);
+        lg_launch_final(a, s, ps.slot ? ps.e0 : nullptr, ps.slot ? ps.e1 : nullptr);
     }
+    return LG_OK;
+}
+
+int make_plan(lg_ctx* h, Plan& pl, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
+              float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, const char* who) {
+    if (!depth || !mask || B <= 0 || H < 8 || W < 8 || W > 8192 || H > 16384)
+        return fail(h, LG_ERR_INVALID, "bad pointer or shape (need H,W >= 8, W <= 8192)");
+    if (pin) pl.P = *pin; else lg_default_params(&pl.P);
+    if (pl.P.stem_se < 1 || pl.P.stem_se > 64 || pl.P.stem_bottom_div < 1)
+        return fail(h, LG_ERR_INVALID, "stem_se must be in [1,64], stem_bottom_div >= 1");
+    pl.B = B; pl.H = H; pl.W = W; pl.WW = (W + 63) / 64;
+    pl.tiles_x = (W + LG_TW - 1) / LG_TW; pl.tiles_y = (H + LG_TH - 1) / LG_TH;
+    if (pl.tiles_x * pl.tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "image too large for the top-k tile table");
+    pl.depth = depth; pl.mask = mask; pl.valid = out_valid;
+    for (int i = 0; i < LG_NUM_MAPS; i++) pl.maps[i] = out_maps ? out_maps[i] : nullptr;
+    (void)who;
+    return LG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
+                  float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, float* theta_host, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    Plan pl;
+    int rc = make_plan(h, pl, depth, mask, B, H, W, pin, out_maps, out_valid, "lg_score_maps");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    rc = ensure_ws(h, B, H, W, pl.P.top_k);
+    if (rc) return rc;
+    for (int i : {LG_MAP_DISTANCE, LG_MAP_TRADITIONAL})
+        if (!pl.maps[i]) {
+            rc = ensure_ws_map(h, i);
+            if (rc) return rc;
+            pl.maps[i] = h->ws_maps[i];
+        }
+    if (!pl.valid) pl.valid = h->ws_valid;
+    rc = enq_prep(h, pl, 0, B, s, h->ev_prep, h->ev_copy);
+    if (rc) return rc;
+    rc = enq_dt(h, pl, 0, B, s);
+    if (rc) return rc;
+    // ---- orientation hand-off: host contour analysis overlaps the distance-transform sweeps
+    LG_HIP(h, hipEventSynchronize(h->ev_copy));
+    host_orient(h, pl, 0, B);
+    if (theta_host)
+        for (int b = 0; b < B; b++) theta_host[b] = h->fp_host[b].theta;
+    rc = enq_final(h, pl, 0, B, s);
+    if (rc) return rc;
     LG_HIP(h, hipGetLastError());
     return LG_OK;
 }
@@ -471,54 +548,121 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                     float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, lg_grasp_result* results, void* stream_) {
     if (!h) return LG_ERR_INVALID;
     if (!results) return fail(h, LG_ERR_INVALID, "lg_select_grasp: results is null");
-    lg_params P;
-    if (pin) P = *pin; else lg_default_params(&P);
+    Plan pl;
+    int rc = make_plan(h, pl, depth, mask, B, H, W, pin, out_maps, out_valid, "lg_select_grasp");
+    if (rc) return rc;
+    const lg_params& P = pl.P;
     if (P.top_k < 1 || P.top_k > 64) return fail(h, LG_ERR_INVALID, "lg_select_grasp: top_k must be in [1,64]");
     hipStream_t s = (hipStream_t)stream_;
     LG_HIP(h, hipSetDevice(h->device));
-    int rc = ensure_ws(h, B, H, W, P.top_k);
+    rc = ensure_ws(h, B, H, W, P.top_k);
     if (rc) return rc;
     const bool use_cnn = h->cnn.loaded;
     // all eight planes are needed when the CNN rescoring runs; otherwise only distance + traditional
-    float* maps[LG_NUM_MAPS];
-    for (int i = 0; i < LG_NUM_MAPS; i++) {
-        maps[i] = out_maps ? out_maps[i] : nullptr;
-        if (!maps[i] && (use_cnn || i == LG_MAP_DISTANCE || i == LG_MAP_TRADITIONAL)) {
+    for (int i = 0; i < LG_NUM_MAPS; i++)
+        if (!pl.maps[i] && (use_cnn || i == LG_MAP_DISTANCE || i == LG_MAP_TRADITIONAL)) {
             rc = ensure_ws_map(h, i);
             if (rc) return rc;
-            maps[i] = h->ws_maps[i];
+            pl.maps[i] = h->ws_maps[i];
         }
-    }
-    uint8_t* valid = out_valid;
-    if (!valid) {
+    if (!pl.valid) {
         if (!h->ws_valid) LG_HIP(h, hipMalloc((void**)&h->ws_valid, (size_t)h->capB * h->capH * h->capW));
-        valid = h->ws_valid;
+        pl.valid = h->ws_valid;
     }
-    std::vector<float> theta(B);
-    rc = lg_score_maps(h, depth, mask, B, H, W, &P, maps, valid, theta.data(), stream_);
-    if (rc) return rc;
     const int K = P.top_k;
-    {
-        ProfScope ps(h, "topk", s);
-        lg_launch_topk(maps[LG_MAP_TRADITIONAL], valid, depth, h->tilekeys, true, B, H, W, K, P.nms_min_distance, h->cand_xy,
-                       h->cand_n, h->cand_info, s);
+    const size_t px = (size_t)H * W;
+    const int tiles = pl.tiles_x * pl.tiles_y;
+
+    // ---- sub-batch pipeline.  Stages per sub-batch k of SB frames:
+    //   D(k): bit rows, stem bits, distance sweeps          -- latency bound, 2*SB workgroups  -> s_dt[k&1]
+    //   F(k): fused score planes                             -- HBM bound                       -> s_main
+    //   T(k): greedy spaced top-k                            -- latency bound, SB workgroups    -> s_topk
+    //   G(k): patch gather + CNN                             -- MFMA bound                      -> s_main
+    // s_main runs F(0) F(1) G(0) F(2) G(1) ... so T(k) hides behind F(k+1) and the D chain behind everything.
+    int SB = B;
+    // Measured on MI355X (B=128, 1080p): SB=32 is 14.8 ms/step vs 11.5 ms unpiped -- the chain
+    // D(0)->F(0)->T(0) must drain before the first CNN launch, and D's latency does not shrink with SB.
+    // Kept for experiments (LG_SUBBATCH=n); the default is one sub-batch.
+    if (const char* e = getenv("LG_SUBBATCH")) SB = std::max(1, atoi(e));
+    const int nsub = (B + SB - 1) / SB;
+    const bool piped = nsub > 1;
+    hipStream_t sD[2] = {piped ? h->s_dt[0] : s, piped ? h->s_dt[1] : s};
+    hipStream_t sM = piped ? h->s_main : s, sT = piped ? h->s_topk : s;
+    while ((int)h->ev_pool.size() < 6 * nsub) {
+        hipEvent_t e;
+        LG_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_pool.push_back(e);
     }
-    if (use_cnn) {
-        {
-            ProfScope ps(h, "gather", s);
-            lg_launch_gather(depth, mask, maps, B, H, W, K, h->cand_xy, h->cand_n, h->patches, s);
+    auto EV = [&](int k, int which) { return h->ev_pool[6 * k + which]; };  // 0 prep 1 copy 2 dt 3 final 4 topk 5 done
+    if (piped) {  // internal streams start after whatever the caller queued on `s`
+        LG_HIP(h, hipEventRecord(h->ev_begin, s));
+        for (hipStream_t q : {sD[0], sD[1], sM, sT}) LG_HIP(h, hipStreamWaitEvent(q, h->ev_begin, 0));
+    }
+    auto enq_G = [&](int k) -> int {
+        const int off = k * SB, n = std::min(SB, B - off);
+        if (piped) LG_HIP(h, hipStreamWaitEvent(sM, EV(k, 4), 0));
+        if (use_cnn) {
+            {
+                ProfScope ps(h, "gather", sM);
+                const float* mp[LG_NUM_MAPS];
+                for (int i = 0; i < LG_NUM_MAPS; i++) mp[i] = pl.maps[i] ? pl.maps[i] + off * px : nullptr;
+                lg_launch_gather(depth + off * px, mask + off * px, mp, n, H, W, K, h->cand_xy + (size_t)off * K * 2,
+                                 h->cand_n + off, h->patches + (size_t)off * K * 9 * 1024, sM);
+            }
+            std::string err;
+            ProfScope ps(h, "cnn", sM);
+            int r2 = lg_cnn_run(&h->cnn, h->patches + (size_t)off * K * 9 * 1024, n * K, h->logits + (size_t)off * K, sM, &err);
+            if (r2) return fail(h, r2, err.c_str());
         }
-        std::string err;
-        ProfScope ps(h, "cnn", s);
-        rc = lg_cnn_run(&h->cnn, h->patches, B * K, h->logits, s, &err);
-        if (rc) return fail(h, rc, err.c_str());
-        LG_HIP(h, hipMemcpyAsync(h->h_logits, h->logits, sizeof(float) * B * K, hipMemcpyDeviceToHost, s));
+        return LG_OK;
+    };
+    // bit rows of the whole batch first (one short kernel) so the host never waits behind a distance sweep
+    rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep, h->ev_copy);
+    if (rc) return rc;
+    if (piped) LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
+    for (int k = 0; k < nsub; k++) {
+        const int off = k * SB, n = std::min(SB, B - off);
+        rc = enq_dt(h, pl, off, n, sD[k & 1]);
+        if (rc) return rc;
+        if (piped) LG_HIP(h, hipEventRecord(EV(k, 2), sD[k & 1]));
     }
+    LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bit rows are on the host; the sweeps are running
+    host_orient(h, pl, 0, B);
+    for (int k = 0; k < nsub; k++) {
+        const int off = k * SB, n = std::min(SB, B - off);
+        if (piped) LG_HIP(h, hipStreamWaitEvent(sM, EV(k, 2), 0));
+        rc = enq_final(h, pl, off, n, sM);
+        if (rc) return rc;
+        if (piped) {
+            LG_HIP(h, hipEventRecord(EV(k, 3), sM));
+            LG_HIP(h, hipStreamWaitEvent(sT, EV(k, 3), 0));
+        }
+        {
+            ProfScope ps(h, "topk", sT);
+            lg_launch_topk(pl.maps[LG_MAP_TRADITIONAL] + off * px, pl.valid + off * px, depth + off * px,
+                           h->tilekeys + (size_t)off * tiles, true, n, H, W, K, P.nms_min_distance,
+                           h->cand_xy + (size_t)off * K * 2, h->cand_n + off, h->cand_info + (size_t)off * K * 2, sT);
+        }
+        if (piped) LG_HIP(h, hipEventRecord(EV(k, 4), sT));
+        if (k >= 1) { rc = enq_G(k - 1); if (rc) return rc; }
+    }
+    rc = enq_G(nsub - 1);
+    if (rc) return rc;
+    if (piped) {  // join: the caller's stream continues after every internal stream
+        for (hipStream_t q : {sD[0], sD[1], sM, sT}) {
+            LG_HIP(h, hipEventRecord(EV(0, 5), q));
+            LG_HIP(h, hipStreamWaitEvent(s, EV(0, 5), 0));
+            LG_HIP(h, hipStreamSynchronize(q));
+        }
+    }
+    if (use_cnn) LG_HIP(h, hipMemcpyAsync(h->h_logits, h->logits, sizeof(float) * B * K, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipMemcpyAsync(h->h_xy, h->cand_xy, sizeof(int32_t) * B * K * 2, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipMemcpyAsync(h->h_n, h->cand_n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipMemcpyAsync(h->h_info, h->cand_info, sizeof(float) * B * K * 2, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipStreamSynchronize(s));
     LG_HIP(h, hipGetLastError());
+    std::vector<float> theta(B);
+    for (int b = 0; b < B; b++) theta[b] = h->fp_host[b].theta;
 
     const int WW = (W + 63) / 64;
     for (int b = 0; b < B; b++) {

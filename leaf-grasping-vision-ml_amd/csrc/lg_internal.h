@@ -59,7 +59,7 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
                          int bottom_start, const LgSeSpans& se, hipStream_t s);
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
                  hipStream_t s);
-void lg_launch_final(const LgFinalArgs& a, hipStream_t s);
+void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
                     bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,
                     float* out_info, hipStream_t s);

@@ -2,6 +2,8 @@
 // Reference semantics: scripts/utils/grasp_point_selector.py (cited per kernel); design: DESIGN.md.
 #include "lg_internal.h"
 
+#include <hip/hip_ext.h>
+
 #include <limits.h>
 
 // ============================================================================ helpers
@@ -309,14 +311,11 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                 uint32_t v[E];
 #pragma unroll
                 for (int k = 0; k < E; k++) {
-                    uint32_t u = p2[k] + LG_C5;
-                    u = min(u, p2[k + 2] + LG_C5);
-                    u = min(u, p1[k] + LG_C5);
-                    u = min(u, p1[k + 1] + LG_B5);
-                    u = min(u, p1[k + 2] + LG_A5);
-                    u = min(u, p1[k + 3] + LG_B5);
-                    u = min(u, p1[k + 4] + LG_C5);
-                    v[k] = min(u, init[k]);
+                    // group equal weights before adding them: min(x+w, y+w) == min(x,y)+w (no overflow, values < 2^31)
+                    const uint32_t mc = min(min(p2[k], p2[k + 2]), min(p1[k], p1[k + 4])) + LG_C5;
+                    const uint32_t mb = min(p1[k + 1], p1[k + 3]) + LG_B5;
+                    const uint32_t ma = p1[k + 2] + LG_A5;
+                    v[k] = min(min(mc, mb), min(ma, init[k]));
                 }
                 // ---- same-row chain: thread-local, then across the workgroup
 #pragma unroll
@@ -656,9 +655,12 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     }
 }
 
-void lg_launch_final(const LgFinalArgs& a, hipStream_t s) {
+void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     long long total = (long long)a.tiles_x * a.tiles_y * a.B;
-    hipLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
+    if (ev_start && ev_stop)  // events stamped by the command processor right around this dispatch
+        hipExtLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, ev_start, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
 }
 
 // ============================================================================ tile keys for an arbitrary (trad, valid) pair
