@@ -169,7 +169,9 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
 int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream);
 
 /* Per-kernel device timing with HIP events recorded on the launch stream (bench.py roofline).
-   lg_profile_enable(h,1) starts collecting; lg_profile_read returns, for kernel `name`
+   lg_profile_enable(h,1) starts collecting for every kernel (an event pair around each launch);
+   lg_profile_enable(h,2) collects only "final", whose dispatch stamps its own start/stop events
+   (hipExtLaunchKernelGGL: no extra packets in the stream); 0 stops.  lg_profile_read returns, for kernel `name`
    ("final", "dt_fwd", "dt_bwd", "prep", "stem", "topk", "gather", "cnn", ...), the number of
    launches and their summed duration in milliseconds since the last enable. */
 int lg_profile_enable(lg_handle h, int on);

@@ -6,8 +6,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -16,6 +20,73 @@
 #include "lg_internal.h"
 
 #define LG_VERSION_STR "leafgrasp-gfx950 0.1"
+
+// Persistent host worker pool (orientation + result post-processing): spawning 16 threads per call costs
+// more than the work itself at B = 128.
+class LgPool {
+public:
+    explicit LgPool(int n) {
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~LgPool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size(); }
+    void run(int n, const std::function<void(int)>& fn) {  // calls fn(0..n-1), returns when all are done
+        if (n <= 0) return;
+        if (n == 1 || th_.empty()) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn; n_ = n; next_.store(0); done_.store(0); gen_++;
+        }
+        cv_.notify_all();
+        work();  // the caller helps
+        std::unique_lock<std::mutex> l(m_);
+        cv_done_.wait(l, [this] { return done_.load() >= n_; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+            if (done_.fetch_add(1) + 1 >= n_) {
+                std::lock_guard<std::mutex> l(m_);
+                cv_done_.notify_all();
+            }
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            if (fn_) work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0;
+    std::atomic<int> next_{0}, done_{0};
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
 
 struct LgProfSlot {
     std::string name;
@@ -42,6 +113,7 @@ struct lg_ctx {
     LgFrameParams* fp_dev = nullptr;
     LgFrameParams* fp_host = nullptr;        // pinned
     unsigned long long* bits_host = nullptr;  // pinned
+    unsigned long long* bits_host_dev = nullptr;  // device-side alias of bits_host (zero-copy export)
     float* ws_maps[LG_NUM_MAPS] = {nullptr};
     uint8_t* ws_valid = nullptr;
     int32_t *cand_xy = nullptr, *cand_n = nullptr;
@@ -50,9 +122,10 @@ struct lg_ctx {
     float *h_info = nullptr, *h_logits = nullptr;
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
-    bool prof_on = false;
+    int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
+    LgPool* pool = nullptr;
 };
 
 namespace {
@@ -83,7 +156,7 @@ struct ProfScope {  // records an event pair around a launch when profiling is o
     hipEvent_t e0 = nullptr;
     bool ext = false;  // true: the launch itself stamps e0/e1 (hipExtLaunchKernelGGL), nothing is recorded here
     ProfScope(lg_ctx* h_, const char* name, hipStream_t s_, bool ext_ = false) : h(h_), s(s_), ext(ext_) {
-        if (!h->prof_on) return;
+        if (!h->prof_on || (h->prof_on == 2 && !ext)) return;
         for (auto& p : h->prof)
             if (p.name == name) slot = &p;
         if (!slot) {
@@ -134,7 +207,7 @@ void free_ws(lg_ctx* h) {
     HF(h->fp_host); HF(h->bits_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
     h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->fp_dev = nullptr;
     h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
-    h->fp_host = nullptr; h->bits_host = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
+    h->fp_host = nullptr; h->bits_host = nullptr; h->bits_host_dev = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
     h->capB = h->capH = h->capW = h->capK = 0;
 }
 
@@ -155,6 +228,10 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, dev_alloc(&h->fp_dev, (size_t)nB));
     LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->bits_host, sizeof(unsigned long long) * words));
+    // LG_EXPORT_KERNEL=1 replaces the D2H memcpy by a 32-workgroup zero-copy kernel (measured slower: the sweeps
+    // finish at 2.23 ms vs 1.73 ms with the memcpy on the priority stream); kept for experiments only.
+    if (!getenv("LG_EXPORT_KERNEL") || hipHostGetDevicePointer((void**)&h->bits_host_dev, h->bits_host, 0) != hipSuccess)
+        h->bits_host_dev = nullptr;
     LG_HIP(h, dev_alloc(&h->cand_xy, (size_t)nB * nK * 2));
     LG_HIP(h, dev_alloc(&h->cand_n, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->cand_info, (size_t)nB * nK * 2));
@@ -181,16 +258,10 @@ void gaussian1d(float k1[5]) {  // ImageProcessor._create_gaussian_kernel, size 
     for (int i = 0; i < 5; i++) k1[i] = (float)(e[i] / s);
 }
 
-void parallel_for(int n, int nthreads, const std::function<void(int)>& fn) {
-    if (n <= 1 || nthreads <= 1) {
+void parallel_for(lg_ctx* h, int n, const std::function<void(int)>& fn) {
+    if (h->pool && n > 1) h->pool->run(n, fn);
+    else
         for (int i = 0; i < n; i++) fn(i);
-        return;
-    }
-    int T = std::min(n, nthreads);
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
-        th.emplace_back([=, &fn]() { for (int i = t; i < n; i += T) fn(i); });
-    for (auto& x : th) x.join();
 }
 
 }  // namespace
@@ -225,7 +296,14 @@ int lg_create(int device, lg_handle* out) {
     lg_ctx* h = new (std::nothrow) lg_ctx();
     if (!h) return LG_ERR_NOMEM;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+    // The side stream is created with the highest priority: ROCm multiplexes normal-priority streams onto a few
+    // in-order hardware queues, and when the side stream lands on the caller's queue the 0.65 ms bit-row export
+    // sits between pack_bits and the sweeps (measured: sweeps finish at 2.4 ms instead of 1.8 ms at B=128).
+    // Priority streams get hardware queues of their own.
+    int prio_least = 0, prio_greatest = 0;
+    if (hipSetDevice(device) == hipSuccess) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess) {
         delete h;
@@ -241,6 +319,8 @@ int lg_create(int device, lg_handle* out) {
     }
     unsigned hw = std::thread::hardware_concurrency();
     h->host_threads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+    if (const char* e = getenv("LG_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
+    h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
 }
@@ -249,6 +329,8 @@ int lg_destroy(lg_handle h) {
     if (!h) return LG_ERR_INVALID;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    delete h->pool;
+    h->pool = nullptr;
     free_ws(h);
     lg_cnn_free(&h->cnn);
     lg_leaf_free(h->leaf);
@@ -270,7 +352,7 @@ const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : "null handl
 int lg_profile_enable(lg_handle h, int on) {
     if (!h) return LG_ERR_INVALID;
     for (auto& p : h->prof) { p.used = 0; p.launches = 0; p.total_ms = 0.0; }
-    h->prof_on = on != 0;
+    h->prof_on = on < 0 ? 0 : on;
     return LG_OK;
 }
 
@@ -313,8 +395,11 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
-    LG_HIP(h, hipMemcpyAsync(h->bits_host + off * words, h->bits + off * words, sizeof(unsigned long long) * n * words,
-                             hipMemcpyDeviceToHost, h->copy_stream));
+    if (h->bits_host_dev && (((off * words) & 1) == 0))   // small-grid export kernel (see lg_export_kernel)
+        lg_launch_export(h->bits + off * words, h->bits_host_dev + off * words, (long long)n * words, h->copy_stream);
+    else
+        LG_HIP(h, hipMemcpyAsync(h->bits_host + off * words, h->bits + off * words, sizeof(unsigned long long) * n * words,
+                                 hipMemcpyDeviceToHost, h->copy_stream));
     LG_HIP(h, hipEventRecord(ev_copy, h->copy_stream));
     return LG_OK;
 }
@@ -347,7 +432,7 @@ void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
     const unsigned long long* hb = h->bits_host;
     LgFrameParams* fph = h->fp_host;
     const int H = pl.H, W = pl.W, WW = pl.WW;
-    parallel_for(n, h->host_threads, [=](int i) {
+    parallel_for(h, n, [=](int i) {
         const int b = off + i;
         double o[5];
         int ok = lg_host_orientation(hb + (size_t)b * H * WW, H, W, WW, o);
@@ -616,6 +701,14 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         }
         return LG_OK;
     };
+    const bool trace = getenv("LG_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    hipEvent_t tev[6] = {nullptr};
+    if (trace) {
+        for (auto& e : tev) hipEventCreate(&e);
+        hipEventRecord(tev[0], s);
+    }
     // bit rows of the whole batch first (one short kernel) so the host never waits behind a distance sweep
     rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep, h->ev_copy);
     if (rc) return rc;
@@ -626,13 +719,18 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         if (rc) return rc;
         if (piped) LG_HIP(h, hipEventRecord(EV(k, 2), sD[k & 1]));
     }
+    if (trace && !piped) hipEventRecord(tev[1], s);   // after the sweeps
+    const double t_enq1 = now();
     LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bit rows are on the host; the sweeps are running
+    const double t_copy = now();
     host_orient(h, pl, 0, B);
+    const double t_orient = now();
     for (int k = 0; k < nsub; k++) {
         const int off = k * SB, n = std::min(SB, B - off);
         if (piped) LG_HIP(h, hipStreamWaitEvent(sM, EV(k, 2), 0));
         rc = enq_final(h, pl, off, n, sM);
         if (rc) return rc;
+        if (trace && !piped) hipEventRecord(tev[2], s);   // after the fused planes
         if (piped) {
             LG_HIP(h, hipEventRecord(EV(k, 3), sM));
             LG_HIP(h, hipStreamWaitEvent(sT, EV(k, 3), 0));
@@ -643,11 +741,13 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                            h->tilekeys + (size_t)off * tiles, true, n, H, W, K, P.nms_min_distance,
                            h->cand_xy + (size_t)off * K * 2, h->cand_n + off, h->cand_info + (size_t)off * K * 2, sT);
         }
+        if (trace && !piped) hipEventRecord(tev[3], s);   // after top-k
         if (piped) LG_HIP(h, hipEventRecord(EV(k, 4), sT));
         if (k >= 1) { rc = enq_G(k - 1); if (rc) return rc; }
     }
     rc = enq_G(nsub - 1);
     if (rc) return rc;
+    if (trace && !piped) hipEventRecord(tev[4], s);       // after gather + CNN
     if (piped) {  // join: the caller's stream continues after every internal stream
         for (hipStream_t q : {sD[0], sD[1], sM, sT}) {
             LG_HIP(h, hipEventRecord(EV(0, 5), q));
@@ -659,28 +759,38 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     LG_HIP(h, hipMemcpyAsync(h->h_xy, h->cand_xy, sizeof(int32_t) * B * K * 2, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipMemcpyAsync(h->h_n, h->cand_n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipMemcpyAsync(h->h_info, h->cand_info, sizeof(float) * B * K * 2, hipMemcpyDeviceToHost, s));
+    const double t_enq2 = now();
     LG_HIP(h, hipStreamSynchronize(s));
+    const double t_sync = now();
     LG_HIP(h, hipGetLastError());
     std::vector<float> theta(B);
     for (int b = 0; b < B; b++) theta[b] = h->fp_host[b].theta;
 
     const int WW = (W + 63) / 64;
-    for (int b = 0; b < B; b++) {
+    LgSeSpans pre_se;
+    lg_make_se_spans(2 * P.pregrasp_clearance + 1, &pre_se);
+    const int32_t* all_xy = h->h_xy;
+    const int32_t* all_n = h->h_n;
+    const float* all_info = h->h_info;
+    const float* all_logits = h->h_logits;
+    const unsigned long long* all_bits = h->bits_host;
+    const float* thp = theta.data();
+    parallel_for(h, B, [=, &P, &pre_se](int b) {
         lg_grasp_result& R = results[b];
         memset(&R, 0, sizeof(R));
-        R.theta = theta[b];
-        const int n = h->h_n[b];
+        R.theta = thp[b];
+        const int n = all_n[b];
         R.n_candidates = n;
-        if (n <= 0) continue;  // reference: "No valid candidate points found" -> (None, None, None)
-        const int32_t* xy = h->h_xy + (size_t)b * K * 2;
-        const float* info = h->h_info + (size_t)b * K * 2;
+        if (n <= 0) return;  // reference: "No valid candidate points found" -> (None, None, None)
+        const int32_t* xy = all_xy + (size_t)b * K * 2;
+        const float* info = all_info + (size_t)b * K * 2;
         int best = 0;
         double best_score = info[0];  // candidate 0's traditional score (grasp_point_selector.py:205-206)
         if (use_cnn && n > 1) {
             for (int i = 0; i < n; i++) {
                 const int x = xy[2 * i], y = xy[2 * i + 1];
                 if (P.mask_is_bool && (x < 16 || y < 16 || x + 16 > W || y + 16 > H)) continue;
-                const double logit = h->h_logits[(size_t)b * K + i];
+                const double logit = all_logits[(size_t)b * K + i];
                 const double sg = 1.0 / (1.0 + exp(-logit));
                 const double ml = tanh(sg * 3.0) * 0.5 + 0.5;               // :133-136
                 const double conf = 1.0 - fabs(ml - 0.5) * 2.0;              // :222
@@ -699,9 +809,9 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         R.X = (float)X; R.Y = (float)Y; R.Z = (float)Z;
         // calculate_pre_grasp_point (:754-819)
         const double nrm = sqrt(X * X + Y * Y + Z * Z);
-        if (!(nrm > 0.0) || !std::isfinite(nrm)) { R.has_pre = 0; continue; }  // reference: exception -> None
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) { R.has_pre = 0; return; }  // reference: exception -> None
         const double dxn = X / nrm, dyn = Y / nrm;
-        const unsigned long long* hb = h->bits_host + (size_t)b * H * WW;
+        const unsigned long long* hb = all_bits + (size_t)b * H * WW;
         bool done = false;
         for (int step = 0; step < 5 && !done; step++) {
             // np.arange(0.05, 0.10, 0.01)[step] = start + step * ((start + delta) - start)
@@ -710,14 +820,24 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
             const int u = (int)((tx * (double)P.f / tz) + (double)P.cx);
             const int v = (int)((ty * (double)P.f / tz) + (double)P.cy);
             if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
-            if (!lg_host_ellipse_hit(hb, H, W, WW, u, v, P.pregrasp_clearance)) {
+            if (!lg_host_ellipse_hit_se(hb, H, W, WW, u, v, pre_se)) {
                 const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
                 if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
             }
         }
         if (!done) { R.pX = (float)(X - dxn * 0.10); R.pY = (float)(Y - dyn * 0.10); R.pZ = (float)Z; }
         R.has_pre = 1;
+    });
+    if (trace && !piped) {
+        float a[5] = {0};
+        for (int i = 1; i <= 4; i++) hipEventElapsedTime(&a[i], tev[0], tev[i]);
+        fprintf(stderr, "[lg] gpu timeline (ms since call start): sweeps done %.3f | planes %.3f | topk %.3f | cnn %.3f\n", a[1], a[2],
+                a[3], a[4]);
     }
+    if (trace) for (auto& e : tev) if (e) hipEventDestroy(e);
+    if (trace)
+        fprintf(stderr, "[lg] B=%d enq1 %.3f | wait bits %.3f | orient %.3f | enq2 %.3f | gpu wait %.3f | post %.3f ms\n", B,
+                t_enq1 - t_start, t_copy - t_enq1, t_orient - t_copy, t_enq2 - t_orient, t_sync - t_enq2, now() - t_sync);
     return LG_OK;
 }
 

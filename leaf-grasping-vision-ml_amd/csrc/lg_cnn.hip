@@ -15,6 +15,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ float lg_zero_pad[4];  // zero-initialised source for padded / out-of-range direct-to-LDS lanes
+
 namespace {
 
 struct LayerCfg { int cin, cinp, cout, wi; bool pool; };
@@ -33,9 +35,15 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
     constexpr int TR = ROWS + 2;                        // staged input rows (halo 1)
     constexpr int TWID = WI + 2;
     constexpr int COUT_T = 64 * CP;                     // output channels per workgroup
-    constexpr int IN_CH_STRIDE = TR * TWID + ((TR * TWID) % 2 == 0 ? 1 : 0);  // odd stride: halves hit other banks
-    __shared__ float s_in[KC * IN_CH_STRIDE];
-    __shared__ __attribute__((aligned(16))) float s_w[9 * KC * COUT_T];
+    constexpr int IN_CH_STRIDE = TR * TWID;             // linear: the LDS image is filled by global_load_lds
+    constexpr int IN_ELEMS = KC * TR * TWID;
+    constexpr int NIN = (IN_ELEMS + 255) / 256;
+    constexpr int IN_PAD = NIN * 256;                   // every lane of every load instruction has a slot
+    constexpr int W4_ELEMS = 9 * KC * (COUT_T / 4);
+    constexpr int NW4 = (W4_ELEMS + 255) / 256;
+    constexpr int BUF = IN_PAD + NW4 * 256 * 4;         // floats per stage
+    // ONE shared object (a second one makes hipcc drain vmcnt before every ds_read): [stage][input | weights]
+    __shared__ __attribute__((aligned(16))) float s_buf[2 * BUF];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wp_i = wave % PP, wc_i = wave / PP;       // pixel-pair / channel-pair of this wave
@@ -66,57 +74,41 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
     const int aoff = (wc_i * 64) + (lane & 31);           // A-operand: channel inside the tile (+32 for block 1)
 
     const float* in_n = in + (size_t)n * CIN * WI * WI;
-    // Software pipeline: the global loads of chunk c+1 are issued into registers before the MFMA loop of
-    // chunk c and written to LDS after it, so HBM/L2 latency hides under the matrix work.
-    constexpr int IN_ELEMS = KC * TR * TWID;
-    constexpr int NIN = (IN_ELEMS + 255) / 256;
-    constexpr int W4_ELEMS = 9 * KC * (COUT_T / 4);
-    constexpr int NW4 = (W4_ELEMS + 255) / 256;
-    float rin[NIN];
-    float4 rw[NW4];
-    auto load_chunk = [&](int c0) {
+    // Direct-to-LDS staging (global_load_lds): chunk c+1 streams into the other LDS stage while the MFMA loop
+    // works on chunk c; no staging registers, no LDS write pass, one barrier per chunk.  The LDS destination of
+    // one wave instruction is wave-uniform base + lane * size, so both images are stored in load order; zero
+    // padding of the conv (and the slots past the end) is fetched from a zeroed device word.
+    auto issue_chunk = [&](int c0, int stage) {
+        float* sb = s_buf + stage * BUF;
 #pragma unroll
         for (int j = 0; j < NIN; j++) {
             const int idx = t + 256 * j;
             const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
             const int ry = r2 / TWID, rx = r2 % TWID;
             const int gy = y0 - 1 + ry, gx = rx - 1, gc = c0 + ci;
-            float v = 0.0f;
-            if (idx < IN_ELEMS && gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI)
-                v = in_n[((size_t)gc * WI + gy) * WI + gx];
-            rin[j] = v;
+            const bool ok = idx < IN_ELEMS && gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
+            const float* src = ok ? in_n + ((size_t)gc * WI + gy) * WI + gx : lg_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NW4; j++) {
             const int idx = t + 256 * j;
             const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
             const int ci = rest % KC, tap = rest / KC;
-            rw[j] = (idx < W4_ELEMS)
-                        ? *reinterpret_cast<const float4*>(wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = (idx < W4_ELEMS) ? wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q : lg_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + IN_PAD + 4 * (256 * j + 64 * wave)),
+                                             16, 0, 0);
         }
     };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int j = 0; j < NIN; j++) {
-            const int idx = t + 256 * j;
-            if (idx < IN_ELEMS) s_in[(idx / (TR * TWID)) * IN_CH_STRIDE + idx % (TR * TWID)] = rin[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NW4; j++) {
-            const int idx = t + 256 * j;
-            if (idx < W4_ELEMS) {
-                const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
-                *reinterpret_cast<float4*>(&s_w[rest * COUT_T + 4 * q]) = rw[j];  // rest = tap*KC + ci
-            }
-        }
-    };
-    load_chunk(0);
-    for (int c0 = 0; c0 < CINP; c0 += KC) {
-        __syncthreads();   // every wave finished reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (c0 + KC < CINP) load_chunk(c0 + KC);
+    issue_chunk(0, 0);
+    int stage = 0;
+    for (int c0 = 0; c0 < CINP; c0 += KC, stage ^= 1) {
+        __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
+        if (c0 + KC < CINP) issue_chunk(c0 + KC, stage ^ 1);
+        const float* s_in = s_buf + stage * BUF;
+        const float* s_w = s_in + IN_PAD;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap % 3;

@@ -113,19 +113,29 @@ void lg_make_se_spans(int k, LgSeSpans* out) {
     }
 }
 
-int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance) {
+int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW, int u, int v, const LgSeSpans& se) {
     // dilated[v,u] != 0  <=>  some set pixel (u+dx, v+dy) with (dy,dx) in the (2c+1) ellipse
-    // (calculate_pre_grasp_point, grasp_point_selector.py:777-779,804)
-    LgSeSpans se;
-    lg_make_se_spans(2 * clearance + 1, &se);
+    // (calculate_pre_grasp_point, grasp_point_selector.py:777-779,804); word-wise span tests on the bit rows
     for (int i = 0; i < se.n; i++) {
         int y = v + i - se.anchor;
         if (y < 0 || y >= H || se.lo[i] > se.hi[i]) continue;
         int x0 = std::max(u + se.lo[i], 0), x1 = std::min(u + se.hi[i], W - 1);
-        for (int x = x0; x <= x1; x++)
-            if ((bits[(size_t)y * WW + (x >> 6)] >> (x & 63)) & 1ull) return 1;
+        if (x0 > x1) continue;
+        const unsigned long long* row = bits + (size_t)y * WW;
+        for (int w = x0 >> 6; w <= (x1 >> 6); w++) {
+            unsigned long long m = ~0ull;
+            if (w == (x0 >> 6)) m &= ~0ull << (x0 & 63);
+            if (w == (x1 >> 6)) m &= ~0ull >> (63 - (x1 & 63));
+            if (row[w] & m) return 1;
+        }
     }
     return 0;
+}
+
+int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance) {
+    LgSeSpans se;
+    lg_make_se_spans(2 * clearance + 1, &se);
+    return lg_host_ellipse_hit_se(bits, H, W, WW, u, v, se);
 }
 
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out) {

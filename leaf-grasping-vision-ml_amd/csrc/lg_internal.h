@@ -55,6 +55,7 @@ struct LgFinalArgs {
 
 // kernel launchers (lg_kernels.hip)
 void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s);
+void lg_launch_export(const unsigned long long* src, unsigned long long* dst_host_devptr, long long nwords, hipStream_t s);
 void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,
                          int bottom_start, const LgSeSpans& se, hipStream_t s);
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
@@ -71,4 +72,5 @@ void lg_launch_gather(const float* depth, const uint8_t* mask, const float* cons
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out);
 // 1 if any set bit of `bits` lies under the (2c+1)^2 ellipse centred at (u,v)  (pre-grasp clearance probe)
 int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance);
+int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW, int u, int v, const LgSeSpans& se);
 void lg_make_se_spans(int k, LgSeSpans* out);
