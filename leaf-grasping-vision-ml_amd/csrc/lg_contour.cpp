@@ -145,19 +145,19 @@ int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, do
     for (int y = 0; y < H; y++) {
         row_start[y] = (int)runs.size();
         const unsigned long long* row = bits + (size_t)y * WW;
-        int x = 0;
         bool in = false;
         int start = 0;
         for (int w = 0; w < WW; w++) {
             unsigned long long v = row[w];
-            if (!in && v == 0) continue;
-            if (in && v == ~0ull && (w + 1) * 64 <= W) continue;
-            for (int b = 0; b < 64; b++) {
-                x = w * 64 + b;
-                if (x >= W) break;
-                bool s = (v >> b) & 1ull;
-                if (s && !in) { in = true; start = x; }
-                else if (!s && in) { in = false; runs.push_back({y, start, x - 1, (int)runs.size()}); }
+            if (w == WW - 1 && (W & 63)) v &= (~0ull) >> (64 - (W & 63));  // ignore padding bits past W
+            // transitions inside the word: bit b of tr is set when pixel b differs from pixel b-1
+            unsigned long long tr = v ^ ((v << 1) | (in ? 1ull : 0ull));
+            while (tr) {
+                const int b = __builtin_ctzll(tr);
+                tr &= tr - 1;
+                const int x = w * 64 + b;
+                if (!in) { in = true; start = x; }
+                else { in = false; runs.push_back({y, start, x - 1, (int)runs.size()}); }
             }
         }
         if (in) runs.push_back({y, start, W - 1, (int)runs.size()});

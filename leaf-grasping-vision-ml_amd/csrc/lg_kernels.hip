@@ -232,9 +232,10 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                                                    int W) {
     constexpr int NW = T / 64;
     constexpr int WP = T * E;
-    constexpr int D = 4;  // rows of global prefetch
-    __shared__ int s_wtot[2][NW];
-    __shared__ uint32_t s_halo[2][NW][4];
+    constexpr int D = (BWD || E > 4) ? 4 : 8;  // rows per prefetch group (two groups are resident)
+    // per row and wave: [0] inclusive wave total, [1..2] lane 0's first two pre-carry values,
+    // [3..4] lane 63's last two pre-carry values, [5] lane 63's wave-local exclusive prefix
+    __shared__ int s_x[2][NW][8];
     const int which = blockIdx.x;
     const int frame = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 
     // raw prefetch registers: forward = E mask bytes (packed in up to 2 dwords), backward = E dwords
     constexpr int RAWN = BWD ? E : (E + 3) / 4;
-    uint32_t raw[D][RAWN];
+    uint32_t raw[D][RAWN], nxt[D][RAWN];  // group being consumed / group in flight
 
     // Branch-free prefetch: addresses are clamped into the image and out-of-image lanes are fixed up by
     // selects, so the compiler keeps the loads in flight (a load inside a divergent branch is waited for
@@ -308,6 +309,10 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     for (int d = 0; d < D; d++) load_row(d, raw[d]);
 
     for (int rb = 0; rb < H; rb += D) {
+        // The whole next group is requested up front, so at the next iteration (where the compiler waits for
+        // everything outstanding at the loop head) the youngest load is D rows old, not one.
+#pragma unroll
+        for (int d = 0; d < D; d++) load_row(rb + D + d, nxt[d]);
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int r = rb + d;
@@ -326,7 +331,6 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                         init[k] = nz ? 0xFFFFFFFFu : 0u;
                     }
                 }
-                load_row(r + D, raw[d]);  // refill the slot just consumed
                 // ---- contributions of the two previous rows
                 uint32_t v[E];
 #pragma unroll
@@ -342,12 +346,24 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                 for (int k = 1; k < E; k++) v[k] = min(v[k], v[k - 1] + LG_A5);
                 int mloc = (int)v[E - 1] - (int)((uint32_t)(c0 + E - 1) * LG_A5);
                 int pin = lg_wave_prefix_min(mloc);
-                if (lane == 63) s_wtot[par][wave] = pin;
-                int excl = lg_wave_shr1(INT_MAX, pin);
+                int excl = lg_wave_shr1(INT_MAX, pin);   // wave-local exclusive prefix
+                // One LDS exchange per row: everything a neighbouring wave needs to rebuild this wave's border
+                // pixels is published BEFORE the barrier (pre-carry values + prefixes); see "rotate" below.
+                if (lane == 0) { s_x[par][wave][1] = (int)v[0]; s_x[par][wave][2] = (int)v[1]; }
+                if (lane == 63) {
+                    s_x[par][wave][0] = pin;
+                    s_x[par][wave][3] = (int)v[E - 2]; s_x[par][wave][4] = (int)v[E - 1];
+                    s_x[par][wave][5] = excl;
+                }
                 lg_lds_barrier();
+                int wpre = INT_MAX, wpre_prev = INT_MAX;  // min of the totals of waves < wave, and < wave-1
 #pragma unroll
-                for (int w = 0; w < NW - 1; w++)
-                    if (w < wave) excl = min(excl, s_wtot[par][w]);
+                for (int w = 0; w < NW - 1; w++) {
+                    const int tw = s_x[par][w][0];
+                    if (w < wave) wpre = min(wpre, tw);
+                    if (w < wave - 1) wpre_prev = min(wpre_prev, tw);
+                }
+                excl = min(excl, wpre);
                 uint32_t cin = (t == 0) ? LG_INF : (uint32_t)(excl + (int)((uint32_t)(c0 - 1) * LG_A5));
 #pragma unroll
                 for (int k = 0; k < E; k++) v[k] = min(v[k], cin + (uint32_t)(k + 1) * LG_A5);
@@ -395,21 +411,34 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                 // ---- rotate row registers, exchange 2-column halos with the neighbouring threads
 #pragma unroll
                 for (int j = 0; j < E + 2; j++) p2[j] = p1[j + 1];
-                if (lane == 0) { s_halo[par][wave][0] = v[0]; s_halo[par][wave][1] = v[1]; }
-                if (lane == 63) { s_halo[par][wave][2] = v[E - 2]; s_halo[par][wave][3] = v[E - 1]; }
                 uint32_t l0 = (uint32_t)lg_wave_shr1((int)LG_INF, (int)v[E - 2]);
                 uint32_t l1 = (uint32_t)lg_wave_shr1((int)LG_INF, (int)v[E - 1]);
                 uint32_t r0 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[0]);
                 uint32_t r1 = (uint32_t)lg_wave_shl1((int)LG_INF, (int)v[1]);
-                lg_lds_barrier();
-                if (lane == 0 && wave > 0) { l0 = s_halo[par][wave - 1][2]; l1 = s_halo[par][wave - 1][3]; }
-                if (lane == 63 && wave < NW - 1) { r0 = s_halo[par][wave + 1][0]; r1 = s_halo[par][wave + 1][1]; }
+                if (lane == 0 && wave > 0) {
+                    // final values of thread t-1 (lane 63 of the previous wave), rebuilt from what it published
+                    const int exl = min(s_x[par][wave - 1][5], wpre_prev);
+                    const uint32_t cprev = (uint32_t)(exl + (int)((uint32_t)(c0 - E - 1) * LG_A5));
+                    l0 = min((uint32_t)s_x[par][wave - 1][3], cprev + (uint32_t)(E - 1) * LG_A5);
+                    l1 = min((uint32_t)s_x[par][wave - 1][4], cprev + (uint32_t)E * LG_A5);
+                }
+                if (lane == 63 && wave < NW - 1) {
+                    // final values of thread t+1 (lane 0 of the next wave): its carry is the prefix over all threads <= t
+                    const int inc = min(s_x[par][wave][0], wpre);
+                    const uint32_t cnext = (uint32_t)(inc + (int)((uint32_t)(c0 + E - 1) * LG_A5));
+                    r0 = min((uint32_t)s_x[par][wave + 1][1], cnext + LG_A5);
+                    r1 = min((uint32_t)s_x[par][wave + 1][2], cnext + 2u * LG_A5);
+                }
                 p1[0] = l0; p1[1] = l1;
 #pragma unroll
                 for (int k = 0; k < E; k++) p1[2 + k] = v[k];
                 p1[E + 2] = r0; p1[E + 3] = r1;
             }
         }
+#pragma unroll
+        for (int d = 0; d < D; d++)
+#pragma unroll
+            for (int q = 0; q < RAWN; q++) raw[d][q] = nxt[d][q];
     }
     if (BWD) {
         mx = lg_wave_max_u32(mx);
