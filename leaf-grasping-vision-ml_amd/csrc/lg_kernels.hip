@@ -801,24 +801,45 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         if (t == 0) s_best = 0;
         if (t < naff) s_keys[(ty_lo + t / ntx) * tiles_x + tx_lo + t % ntx] = 0;
         __syncthreads();
-        const int chunks = naff * (LG_TW * LG_TH / LG_TOPK_T);  // chunks of 1024 pixels, 2 per tile
-        for (int c = 0; c < chunks; c++) {
-            const int ta = c / (LG_TW * LG_TH / LG_TOPK_T);
-            const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
-            const int li = (c % (LG_TW * LG_TH / LG_TOPK_T)) * LG_TOPK_T + t;
-            const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
-            unsigned long long key = 0;
-            if (x < W && y < H) {
-                bool dead = false;
-                for (int q = 0; q <= r; q++) dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
-                if (!dead) {
-                    size_t o = fo + (size_t)y * W + x;
-                    float sc = valid[o] ? trad[o] : 0.0f;
-                    key = ((unsigned long long)lg_orderable(sc) << 32) | (uint32_t)(y * W + x);
+        // 1024-pixel chunks, 2 per tile.  Loads of up to 12 chunks are issued together (one round trip to L2/HBM
+        // instead of one per chunk: each round of the greedy walk is a dependent chain, latency is everything).
+        constexpr int CPT = LG_TW * LG_TH / LG_TOPK_T;
+        const int chunks = naff * CPT;
+        constexpr int GRP = 12;
+        for (int cb = 0; cb < chunks; cb += GRP) {
+            float sc_[GRP];
+            int idx_[GRP], tile_[GRP];
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+                const int c = cb + g;
+                sc_[g] = 0.0f; idx_[g] = -1; tile_[g] = 0;
+                if (c < chunks) {
+                    const int ta = c / CPT;
+                    const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
+                    const int li = (c % CPT) * LG_TOPK_T + t;
+                    const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
+                    tile_[g] = tile;
+                    if (x < W && y < H) {
+                        const size_t o = fo + (size_t)y * W + x;
+                        idx_[g] = y * W + x;
+                        sc_[g] = valid[o] ? trad[o] : 0.0f;
+                    }
                 }
             }
-            key = lg_wave_max_u64(key);
-            if ((t & 63) == 0 && key) atomicMax(&s_keys[tile], key);
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+                if (cb + g < chunks) {   // uniform across the workgroup
+                    unsigned long long key = 0;
+                    if (idx_[g] >= 0) {
+                        const int x = idx_[g] % W, y = idx_[g] / W;
+                        bool dead = false;
+                        for (int q = 0; q <= r; q++) dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
+                        if (!dead) key = ((unsigned long long)lg_orderable(sc_[g]) << 32) | (uint32_t)idx_[g];
+                    }
+                    key = lg_wave_max_u64(key);
+                    if ((t & 63) == 0 && key) atomicMax(&s_keys[tile_[g]], key);
+                }
+            }
         }
         __syncthreads();
     }
