@@ -473,3 +473,114 @@ int lg_greedy_nms(const int64_t* order, int64_t n, int H, int W, int top_k, int 
     free(used);
     return cnt;
 }
+
+/* ------------------------------------------------------------------------ */
+/*
+ * Second-order fast-marching distance, restating skfmm.distance(phi, dx=1) of scikit-fmm 2022.3.26
+ * (requirements.txt:5; NOT installed here) for the one call site on the hot path,
+ * leaf_scorer.py:67-69: phi = 0 on every leaf pixel, 1 elsewhere.  Cells with phi == 0 are frozen at
+ * distance 0; there is no sign change, so every other cell is solved from them with the upwind
+ * quadratic  sum_dim max(D-_ij u, 0)^2 = 1, second-order one-sided differences (coefficients 9/4,
+ * (4 u1 - u2)/3) when two upwind frozen neighbours are available and monotone, first order otherwise,
+ * cells finalised in increasing order from a binary heap.  Used ONLY to quantify how far the build's
+ * exact-EDT semantics can move the consumed arg-max (tests/test_oracle_fmm.py).  PARITY UNPINNED.
+ */
+typedef struct { double v; int idx; } lg_hn;
+static void lg_heap_up(lg_hn* h, int* pos, int i) {
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (h[p].v <= h[i].v) break;
+        lg_hn t = h[p]; h[p] = h[i]; h[i] = t;
+        pos[h[p].idx] = p; pos[h[i].idx] = i;
+        i = p;
+    }
+}
+static void lg_heap_down(lg_hn* h, int* pos, int n, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l].v < h[m].v) m = l;
+        if (r < n && h[r].v < h[m].v) m = r;
+        if (m == i) break;
+        lg_hn t = h[m]; h[m] = h[i]; h[i] = t;
+        pos[h[m].idx] = m; pos[h[i].idx] = i;
+        i = m;
+    }
+}
+static double lg_fmm_update(const double* d, const uint8_t* frozen, int H, int W, int y, int x) {
+    double a = 0, b = 0, c = -1.0;
+    int dim;
+    for (dim = 0; dim < 2; dim++) {
+        double v1 = 1e300, v2 = 1e300;
+        int j;
+        for (j = -1; j <= 1; j += 2) {
+            int yy = y + (dim == 0 ? j : 0), xx = x + (dim == 1 ? j : 0);
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W || !frozen[yy * W + xx]) continue;
+            if (d[yy * W + xx] < v1) {
+                int y2 = y + (dim == 0 ? 2 * j : 0), x2 = x + (dim == 1 ? 2 * j : 0);
+                v1 = d[yy * W + xx];
+                if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W && frozen[y2 * W + x2] && d[y2 * W + x2] <= v1)
+                    v2 = d[y2 * W + x2];
+                else
+                    v2 = 1e300;
+            }
+        }
+        if (v2 < 1e300) {
+            double tp = (4.0 * v1 - v2) / 3.0, aa = 9.0 / 4.0;
+            a += aa; b -= 2.0 * aa * tp; c += aa * tp * tp;
+        } else if (v1 < 1e300) {
+            a += 1.0; b -= 2.0 * v1; c += v1 * v1;
+        }
+    }
+    {
+        double det = b * b - 4.0 * a * c;
+        if (a == 0) return 1e300;
+        if (det < 0) det = 0;
+        return (-b + sqrt(det)) / (2.0 * a);
+    }
+}
+void lg_fmm_distance(const uint8_t* leaf, int H, int W, double* dist) {
+    int n = H * W, i, hn = 0;
+    uint8_t* frozen = (uint8_t*)calloc(n, 1);
+    int* pos = (int*)malloc(sizeof(int) * n);
+    lg_hn* heap = (lg_hn*)malloc(sizeof(lg_hn) * n);
+    static const int dy4[4] = {-1, 1, 0, 0}, dx4[4] = {0, 0, -1, 1};
+    for (i = 0; i < n; i++) { pos[i] = -1; dist[i] = leaf[i] ? 0.0 : 1e300; frozen[i] = leaf[i] ? 1 : 0; }
+    for (i = 0; i < n; i++) {
+        int y = i / W, x = i % W, k;
+        if (frozen[i]) continue;
+        for (k = 0; k < 4; k++) {
+            int yy = y + dy4[k], xx = x + dx4[k];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W && frozen[yy * W + xx]) {
+                double v = lg_fmm_update(dist, frozen, H, W, y, x);
+                dist[i] = v;
+                heap[hn].v = v; heap[hn].idx = i; pos[i] = hn; lg_heap_up(heap, pos, hn); hn++;
+                break;
+            }
+        }
+    }
+    while (hn > 0) {
+        lg_hn top = heap[0];
+        int y = top.idx / W, x = top.idx % W, k;
+        hn--;
+        if (hn > 0) { heap[0] = heap[hn]; pos[heap[0].idx] = 0; lg_heap_down(heap, pos, hn, 0); }
+        pos[top.idx] = -1;
+        frozen[top.idx] = 1;
+        dist[top.idx] = top.v;
+        for (k = 0; k < 4; k++) {
+            int yy = y + dy4[k], xx = x + dx4[k], q;
+            double v;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            q = yy * W + xx;
+            if (frozen[q]) continue;
+            v = lg_fmm_update(dist, frozen, H, W, yy, xx);
+            if (pos[q] < 0) {
+                dist[q] = v;
+                heap[hn].v = v; heap[hn].idx = q; pos[q] = hn; lg_heap_up(heap, pos, hn); hn++;
+            } else if (v < heap[pos[q]].v) {
+                heap[pos[q]].v = v; dist[q] = v; lg_heap_up(heap, pos, pos[q]);
+            }
+        }
+    }
+    for (i = 0; i < n; i++) if (dist[i] >= 1e299) dist[i] = 0.0;  /* no leaf at all */
+    free(frozen); free(pos); free(heap);
+}

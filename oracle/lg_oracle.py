@@ -62,6 +62,8 @@ def _lib():
         L.lg_greedy_nms.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
         L.lg_greedy_nms.restype = ctypes.c_int
+        L.lg_fmm_distance.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.lg_fmm_distance.restype = None
         _LIB = L
     return _LIB
 
@@ -520,18 +522,29 @@ def visibility_score(leaf_mask):
     return 1.0 - d / np.sqrt((w / 2) ** 2 + (h / 2) ** 2)
 
 
-def clutter_extrema(labels):
+def clutter_extrema(labels, method="edt"):
     """leaf_scorer.py:66-71.  The reference runs skfmm.distance (scikit-fmm 2022.3.26, absent here)
     on phi = 0 on any leaf / 1 elsewhere and only consumes argmin / argmax.  Build semantics
-    (DESIGN.md): exact Euclidean distance to the nearest leaf pixel; argmin = first leaf pixel,
-    argmax = first maximum in row-major order.  PARITY UNPINNED vs scikit-fmm."""
+    (DESIGN.md): method="edt" = exact Euclidean distance to the nearest leaf pixel; argmin = first leaf
+    pixel, argmax = first maximum in row-major order.  method="fmm" = the restated second-order fast
+    marching field (fmm_distance), used to measure how far the semantics can move the arg-max.
+    PARITY UNPINNED vs scikit-fmm."""
     from scipy import ndimage
 
     leaf = np.asarray(labels) >= 1
-    field = ndimage.distance_transform_edt(~leaf)
+    field = ndimage.distance_transform_edt(~leaf) if method == "edt" else fmm_distance(leaf)
     mn = np.unravel_index(field.argmin(), field.shape)
     mx = np.unravel_index(field.argmax(), field.shape)
     return mn, mx
+
+
+def fmm_distance(leaf_bool):
+    """Restated second-order fast marching (what skfmm.distance does at leaf_scorer.py:69); see lg_oracle.c.
+    Only used to quantify the EDT-vs-FMM deviation of the consumed arg-max.  PARITY UNPINNED."""
+    a, p = _u8(np.asarray(leaf_bool).astype(np.uint8))
+    out = np.empty(a.shape, np.float64)
+    _lib().lg_fmm_distance(p, a.shape[0], a.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out
 
 
 def pareto_max(scores):
@@ -553,9 +566,10 @@ def pareto_max(scores):
 class RefOptimalLeafSelector:
     """Restatement of scripts/utils/leaf_scorer.py::OptimalLeafSelector.select_optimal_leaf (:25-203)."""
 
-    def __init__(self):
+    def __init__(self, field="edt"):
         self.camera_cx = self.camera_cy = self.f_norm = None
         self._tall_leaves = []
+        self.field = field  # "edt" (build semantics) or "fmm" (restated scikit-fmm behaviour)
 
     def set_camera_params(self, P):  # :19-23
         self.f_norm, self.camera_cx, self.camera_cy = P[0, 0], P[0, 2], P[1, 2]
@@ -578,7 +592,7 @@ class RefOptimalLeafSelector:
             return None
         depth_mean = np.mean(np.array(depth_list))
         tall = [int(leaf_ids[i]) for i, d in enumerate(depth_list) if d < depth_mean]
-        mn, mx = clutter_extrema(mask_np)
+        mn, mx = clutter_extrema(mask_np, self.field)
         cands = []
         for idx, lid in enumerate(leaf_ids):
             lm = leaf_masks[idx]
