@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblgrasp.so")
+LIB_PATH = os.environ.get("LG_LIB_PATH") or os.path.join(_HERE, "liblgrasp.so")  # override: kernel experiments only
 
 LG_NUM_MAPS = 8
 MAP_NAMES = ("sdf_score", "approach_score", "flatness_map", "isolation_map", "distance_map",

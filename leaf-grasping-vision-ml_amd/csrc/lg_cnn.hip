@@ -78,25 +78,43 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
     // works on chunk c; no staging registers, no LDS write pass, one barrier per chunk.  The LDS destination of
     // one wave instruction is wave-uniform base + lane * size, so both images are stored in load order; zero
     // padding of the conv (and the slots past the end) is fetched from a zeroed device word.
+    // Source offsets are chunk-invariant apart from the channel base: computed once, so issuing a chunk costs a
+    // few VALU instructions per load instead of ~25 (the two workgroups of a CU run in lock-step; address math
+    // at every chunk boundary would leave the MFMA pipe idle on both).
+    int off_in[NIN];   // offset inside the chunk's first channel plane group, or -1: zero padding / unused slot
+    int ci_in[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int idx = t + 256 * j;
+        const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
+        const int ry = r2 / TWID, rx = r2 % TWID;
+        const int gy = y0 - 1 + ry, gx = rx - 1;
+        const bool ok = idx < IN_ELEMS && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
+        off_in[j] = ok ? (ci * WI + gy) * WI + gx : -1;
+        ci_in[j] = ci;
+    }
+    int off_w[NW4];    // offset into the packed weights for c0 = 0, or -1
+#pragma unroll
+    for (int j = 0; j < NW4; j++) {
+        const int idx = t + 256 * j;
+        const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
+        const int ci = rest % KC, tap = rest / KC;
+        off_w[j] = (idx < W4_ELEMS) ? (tap * CINP + ci) * COUT + co0 + 4 * q : -1;
+    }
     auto issue_chunk = [&](int c0, int stage) {
         float* sb = s_buf + stage * BUF;
+        const float* in_c = in_n + (size_t)c0 * WI * WI;
+        const float* w_c = wp + (size_t)c0 * COUT;
 #pragma unroll
         for (int j = 0; j < NIN; j++) {
-            const int idx = t + 256 * j;
-            const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
-            const int ry = r2 / TWID, rx = r2 % TWID;
-            const int gy = y0 - 1 + ry, gx = rx - 1, gc = c0 + ci;
-            const bool ok = idx < IN_ELEMS && gc < CIN && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
-            const float* src = ok ? in_n + ((size_t)gc * WI + gy) * WI + gx : lg_zero_pad;
+            const bool ok = off_in[j] >= 0 && (CIN == CINP || c0 + ci_in[j] < CIN);
+            const float* src = ok ? in_c + off_in[j] : lg_zero_pad;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NW4; j++) {
-            const int idx = t + 256 * j;
-            const int q = idx % (COUT_T / 4), rest = idx / (COUT_T / 4);
-            const int ci = rest % KC, tap = rest / KC;
-            const float* src = (idx < W4_ELEMS) ? wp + ((size_t)(tap * CINP + c0 + ci)) * COUT + co0 + 4 * q : lg_zero_pad;
+            const float* src = off_w[j] >= 0 ? w_c + off_w[j] : lg_zero_pad;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sb + IN_PAD + 4 * (256 * j + 64 * wave)),
                                              16, 0, 0);
