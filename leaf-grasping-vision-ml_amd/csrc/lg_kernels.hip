@@ -37,13 +37,27 @@ __device__ __forceinline__ int lg_wave_shl1(int old, int v) {  // lane i <- lane
 // every image row of the distance-transform sweeps on its own global prefetch (rows are ~1000 cycles apart,
 // HBM latency is longer): LDS operations are complete at lgkmcnt(0), global loads/stores stay in flight.
 __device__ __forceinline__ void lg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ unsigned long long lg_wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        unsigned long long w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
+// max of a 64-bit key over the wave, returned in every lane.  DPP row shifts / row broadcasts on the two
+// halves (a ds_bpermute shuffle costs ~100+ cycles of latency per step; the top-k walk does 13 of these per round).
+#define LG_MAX64_STEP(CTRL, RMASK)                                                            \
+    {                                                                                         \
+        const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, RMASK, 0xf, false); \
+        const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, RMASK, 0xf, false); \
+        const bool take = (oh > hi) || (oh == hi && ol > lo);                                 \
+        hi = take ? oh : hi;                                                                  \
+        lo = take ? ol : lo;                                                                  \
     }
-    return v;
+__device__ __forceinline__ unsigned long long lg_wave_max_u64(unsigned long long v) {
+    uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    LG_MAX64_STEP(0x111, 0xf)  // row_shr:1
+    LG_MAX64_STEP(0x112, 0xf)  // row_shr:2
+    LG_MAX64_STEP(0x114, 0xf)  // row_shr:4
+    LG_MAX64_STEP(0x118, 0xf)  // row_shr:8
+    LG_MAX64_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1,3
+    LG_MAX64_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2,3
+    hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t lg_wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -799,10 +813,6 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
             s_cx[r] = px; s_cy[r] = py;
             out_xy[((size_t)frame * k + r) * 2 + 0] = px;
             out_xy[((size_t)frame * k + r) * 2 + 1] = py;
-            if (out_info) {
-                out_info[((size_t)frame * k + r) * 2 + 0] = trad[fo + idx];
-                out_info[((size_t)frame * k + r) * 2 + 1] = depth ? depth[fo + idx] : 0.0f;
-            }
         }
         n = r + 1;
         // tiles touched by the new suppression window
@@ -857,6 +867,13 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         __syncthreads();
     }
     if (t == 0) out_n[frame] = n;
+    // traditional score + depth at the picks, gathered once after the walk (a dependent global load inside
+    // every round would sit on the critical path of the next arg-max)
+    if (out_info && t < n) {
+        const size_t o = fo + (size_t)s_cy[t] * W + s_cx[t];
+        out_info[((size_t)frame * k + t) * 2 + 0] = trad[o];
+        out_info[((size_t)frame * k + t) * 2 + 1] = depth ? depth[o] : 0.0f;
+    }
 }
 
 void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
