@@ -246,3 +246,54 @@ def test_error_convention(L):
     s.set_camera_params(np.array([[100.0, 0, 32, -10], [0, 100, 32, 0], [0, 0, 1, 0]]))
     assert s.select_grasp_point(m[:4, :4], d[:4, :4], None) == (None, None, None)  # unsupported shape -> logged, not raised
     assert s.get_ml_score(m, d, {}, (10, 10)) is None
+
+
+# ----------------------------------------------------------------------------- batches, pipeline variant, robustness
+def test_batched_select_equals_single_calls_1080p(sel):
+    """BASELINE config 3 per-GPU share in miniature: a batch of 1080p frames gives exactly the per-frame results."""
+    H, W = 1080, 1920
+    frames = [O.synthetic_scene(H, W, 100 + s) for s in range(3)]
+    P = frames[0][2]
+    sel.set_camera_params(P)
+    sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
+    order = [0, 1, 2, 1, 0, 2, 2, 0]
+    masks = torch.from_numpy(np.stack([frames[i][0] == 1 for i in order])).cuda()
+    depths = torch.from_numpy(np.stack([frames[i][1] for i in order])).cuda()
+    batch = sel.select_grasp_points_batch(masks, depths)
+    singles = [sel.select_grasp_point(masks[i], depths[i], None) for i in range(3)]
+    for j, i in enumerate(order):
+        assert batch[j] == singles[i]
+    # the experimental sub-batch pipeline (multi-stream) must give identical results
+    import os
+    os.environ["LG_SUBBATCH"] = "3"
+    try:
+        assert sel.select_grasp_points_batch(masks, depths) == batch
+    finally:
+        del os.environ["LG_SUBBATCH"]
+    sel.clear_cnn()
+
+
+def test_non_finite_depth_does_not_hang_or_raise(sel):
+    H, W = 270, 360
+    labels, depth, P = O.synthetic_scene(H, W, 1)
+    sel.set_camera_params(P)
+    d = depth.copy()
+    d[100:140, 150:200] = np.nan
+    d[10, 10] = np.inf
+    res = sel.select_grasp_point(torch.from_numpy(labels == 1).cuda(), torch.from_numpy(d).cuda(), None)
+    assert isinstance(res, tuple) and len(res) == 3
+    maps, valid, _ = sel.score_maps(torch.from_numpy((labels == 1).astype(np.uint8)).cuda(), torch.from_numpy(d).cuda())
+    dm = maps["distance_map"].cpu().numpy()
+    np.testing.assert_array_equal(dm, O.distance_transform((labels == 1).astype(np.uint8), 5))  # depth never touches the DT
+
+
+def test_uint8_mask_with_255_values(sel):
+    H, W = 270, 360
+    labels, depth, P = O.synthetic_scene(H, W, 2)
+    sel.set_camera_params(P)
+    m1 = (labels == 1).astype(np.uint8)
+    a, va, _ = sel.score_maps(torch.from_numpy(m1).cuda(), torch.from_numpy(depth).cuda())
+    b, vb, _ = sel.score_maps(torch.from_numpy(m1 * 255).cuda(), torch.from_numpy(depth).cuda())
+    for k in a:
+        np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
+    np.testing.assert_array_equal(va.cpu().numpy(), vb.cpu().numpy())
