@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 #   read depth f32 4 + distance_map f32 4 + mask bits 1/8 + stem bits 1/8; write 7 f32 planes 28 + valid u8 1
 FINAL_BYTES_PER_PX = 4 + 4 + 0.125 + 0.125 + 28 + 1
 PATH_BYTES_PER_PX = 38.0  # whole-path compulsory traffic per pixel
+CPU_BASELINE_THREADS = 16  # one GPU's share of the box's host cores (torch intra-op threads of the CPU leg)
 
 
 def make_frames(B, H, W, n_distinct=4):
@@ -54,6 +55,7 @@ def cpu_baseline(H, W, P, params, n_frames):
     (OpenCV / scikit-fmm are absent from this image)."""
     from oracle import lg_oracle as O
 
+    torch.set_num_threads(CPU_BASELINE_THREADS)
     ref = O.RefGraspPointSelector(cnn=lambda x: O.cnn_forward(params, x))
     ref.set_camera_params(P)
     times = []
@@ -233,9 +235,10 @@ def main():
             times = cpu_baseline(H, W, P, params, args.cpu_frames)
             out["cpu_baseline"] = {
                 "value": round(len(times) / sum(times), 4), "unit": "frames/s",
-                "cores": int(torch.get_num_threads()), "kind": "port",
+                "cores": CPU_BASELINE_THREADS, "kind": "port",
                 "sample": f"{len(times)} synthetic {H}x{W} frames through oracle/lg_oracle.py "
-                          f"(restated NumPy/torch-CPU + C chamfer path, numpy argsort, 20 batch-1 CNN forwards); "
+                          f"(restated NumPy/torch-CPU + C chamfer path, numpy argsort, 20 batch-1 CNN forwards; "
+                          f"NumPy planes single-threaded, torch CPU ops on {CPU_BASELINE_THREADS} threads); "
                           f"os.cpu_count()={os.cpu_count()}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
