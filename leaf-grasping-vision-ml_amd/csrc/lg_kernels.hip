@@ -591,23 +591,50 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     __syncthreads();
     // ---- separable 5-tap Gaussian; g is stored at the *reflect-padded* coordinates the Sobel stage reads
     //      (F.pad(g,(1,1,1,1),'reflect'), grasp_point_selector.py:648): g_ext(e) = G(reflect1(e)).
-    for (int idx = t; idx < DH * GW; idx += 256) {
-        int er = idx / GW, ec = idx % GW;
-        int x = lg_reflect(tx0 - 1 + ec, W);
-        int lc = x - (tx0 - 4);
+    // Work split without div/mod: thread t owns column (t & 63) for rows (t >> 6) + 4k; the two extra halo
+    // columns (64, 65) are covered by the first threads afterwards.
+    {
+        const int ec = t & 63;
+        int lc = lg_reflect(tx0 - 1 + ec, W) - (tx0 - 4);
         lc = lc < 2 ? 2 : (lc > DW - 3 ? DW - 3 : lc);
-        const float* p = &s_dm[er * DW + lc - 2];
-        s_h[idx] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+#pragma unroll
+        for (int k = 0; k < (DH + 3) / 4; k++) {
+            const int er = (t >> 6) + 4 * k;
+            if (er < DH) {
+                const float* p = &s_dm[er * DW + lc - 2];
+                s_h[er * GW + ec] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+            }
+        }
+        if (t < 2 * DH) {
+            const int er = t >> 1, ec2 = 64 + (t & 1);
+            int lc2 = lg_reflect(tx0 - 1 + ec2, W) - (tx0 - 4);
+            lc2 = lc2 < 2 ? 2 : (lc2 > DW - 3 ? DW - 3 : lc2);
+            const float* p = &s_dm[er * DW + lc2 - 2];
+            s_h[er * GW + ec2] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+        }
     }
     __syncthreads();
-    for (int idx = t; idx < GH * GW; idx += 256) {
-        int gr = idx / GW, ec = idx % GW;
-        int y = lg_reflect(ty0 - 1 + gr, H);
-        int lr = y - (ty0 - 3);
-        lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
-        const float* p = &s_h[(lr - 2) * GW + ec];
-        s_g[gr * (GW + 2) + ec] =
-            a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+    {
+        const int ec = t & 63;
+#pragma unroll
+        for (int k = 0; k < (GH + 3) / 4; k++) {
+            const int gr = (t >> 6) + 4 * k;
+            if (gr < GH) {
+                int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
+                lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
+                const float* p = &s_h[(lr - 2) * GW + ec];
+                s_g[gr * (GW + 2) + ec] =
+                    a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+            }
+        }
+        if (t < 2 * GH) {
+            const int gr = t >> 1, ec2 = 64 + (t & 1);
+            int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
+            lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
+            const float* p = &s_h[(lr - 2) * GW + ec2];
+            s_g[gr * (GW + 2) + ec2] =
+                a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+        }
     }
     __syncthreads();
 
