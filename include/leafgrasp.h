@@ -61,7 +61,8 @@ enum {
 
 /* Every constant of the path; lg_default_params fills the reference values. */
 typedef struct lg_params {
-    float cx, cy, f;                 /* camera: P[0,2], P[1,2], P[0,0]  (:145-150); defaults 707, 494, 0 (unset) */
+    double cx, cy, f;                /* camera: P[0,2], P[1,2], P[0,0]  (:145-150); defaults 707, 494, 0 (unset).
+                                        double: x - cx cancels catastrophically in float32 next to the optical centre */
     float w_approach, w_sdf, w_flat, w_access;      /* 0.4 0.3 0.2 0.1            (:272-277) */
     float sdf_w_interior, sdf_w_align, sdf_w_sdf;   /* 0.4 0.4 0.2                (:563-565) */
     float optimal_distance;                         /* 20 px                      (:535-536) */

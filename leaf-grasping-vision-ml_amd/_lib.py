@@ -15,8 +15,8 @@ LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_NOMEM, LG_ERR_NO_MODEL, LG_ERR_UNSUPPO
 
 
 class LgParams(C.Structure):
-    _fields_ = [(n, C.c_float) for n in (
-        "cx", "cy", "f", "w_approach", "w_sdf", "w_flat", "w_access", "sdf_w_interior", "sdf_w_align",
+    _fields_ = [(n, C.c_double) for n in ("cx", "cy", "f")] + [(n, C.c_float) for n in (
+        "w_approach", "w_sdf", "w_flat", "w_access", "sdf_w_interior", "sdf_w_align",
         "sdf_w_sdf", "optimal_distance", "access_w_dist", "access_w_dir", "flat_scale", "iso_w_close",
         "iso_w_wide", "iso_ramp_top", "iso_ramp_bottom", "min_edge_distance", "stem_valid_thresh")] + \
         [(n, C.c_int32) for n in ("stem_se", "stem_bottom_div", "top_k", "nms_min_distance",

@@ -273,7 +273,7 @@ const char* lg_version(void) { return LG_VERSION_STR; }
 void lg_default_params(lg_params* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));
-    p->cx = 707.f; p->cy = 494.f; p->f = 0.f;  // grasp_point_selector.py:29-31 (f_norm unset)
+    p->cx = 707.0; p->cy = 494.0; p->f = 0.0;  // grasp_point_selector.py:29-31 (f_norm unset)
     p->w_approach = 0.4f; p->w_sdf = 0.3f; p->w_flat = 0.2f; p->w_access = 0.1f;
     p->sdf_w_interior = 0.4f; p->sdf_w_align = 0.4f; p->sdf_w_sdf = 0.2f;
     p->optimal_distance = 20.f;
@@ -459,7 +459,8 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     a.valid = pl.valid ? pl.valid + off * px : nullptr;
     a.tilekeys = h->tilekeys + (size_t)off * pl.tiles_x * pl.tiles_y;
     a.B = n; a.H = H; a.W = W; a.WW = pl.WW; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
-    a.cx = P.cx; a.cy = P.cy; a.f = P.f;
+    a.cxi = (int)floor(P.cx); a.cyi = (int)floor(P.cy);
+    a.cxf = (float)(P.cx - floor(P.cx)); a.cyf = (float)(P.cy - floor(P.cy)); a.f = (float)P.f;
     a.w_approach = P.w_approach; a.w_sdf = P.w_sdf; a.w_flat = P.w_flat; a.w_access = P.w_access;
     a.sdf_w_interior = P.sdf_w_interior; a.sdf_w_align = P.sdf_w_align; a.sdf_w_sdf = P.sdf_w_sdf;
     a.optimal_distance = P.optimal_distance;

@@ -42,7 +42,8 @@ struct LgFinalArgs {
     uint8_t* valid;               // [B][H][W] or null
     unsigned long long* tilekeys; // [B][tiles]
     int B, H, W, WW, tiles_x, tiles_y;
-    float cx, cy, f;
+    int cxi, cyi;      // floor of the optical centre; (x - cxi) is exact, the fraction is subtracted afterwards
+    float cxf, cyf, f;  // fractions in [0,1) and the focal length
     float w_approach, w_sdf, w_flat, w_access;
     float sdf_w_interior, sdf_w_align, sdf_w_sdf, optimal_distance;
     float access_w_dist, access_w_dir, flat_scale;

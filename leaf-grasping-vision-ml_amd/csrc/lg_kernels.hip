@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
                 gb[0] = b4.x; gb[1] = b4.y; gb[2] = b4.z; gb[3] = b4.w; gb[4] = b2.x; gb[5] = b2.y;
                 gc[0] = c4.x; gc[1] = c4.y; gc[2] = c4.z; gc[3] = c4.w; gc[4] = c2.x; gc[5] = c2.y;
             }
-            const float dyp = (float)y - a.cy;
+            const float dyp = (float)(y - a.cyi) - a.cyf;  // exact integer part first: no cancellation near the centre
             const int dyb = min(y + 1, H - y);
             const float ramp = a.iso_ramp_top + ramp_step * (float)y;
             float o_sdf[4], o_app[4], o_flat[4], o_iso[4], o_acc[4], o_stem[4], o_trad[4];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
                 float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
                 float flat = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(sx * sx + sy * sy));  // v_sqrt_f32, 1 ulp
                 // closed-form geometry planes                                           (:502-524, :569-593)
-                const float dxp = (float)x - a.cx;
+                const float dxp = (float)(x - a.cxi) - a.cxf;
                 const float r2 = dxp * dxp + dyp * dyp;
                 const float inv_r = r2 > 0.0f ? rsqrtf(r2) : 0.0f;
                 const float r = r2 * inv_r;

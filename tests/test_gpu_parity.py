@@ -297,3 +297,24 @@ def test_uint8_mask_with_255_values(sel):
     for k in a:
         np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
     np.testing.assert_array_equal(va.cpu().numpy(), vb.cpu().numpy())
+
+
+def test_optical_centre_pixel_precision(sel):
+    """Regression (found by tools/stress_parity.py): x - cx cancels in float32 for the pixel next to the optical
+    centre (r = 0.08 px here) unless the integer part is subtracted exactly first."""
+    labels, depth, P = O.synthetic_scene(284, 537, 1072)
+    _compare_maps(sel, (labels == 1).astype(np.uint8), depth, P)
+
+
+def test_randomised_sweep_small(sel):
+    """A slice of tools/stress_parity.py: odd sizes, multi-component masks, specks, border contact."""
+    rng = np.random.default_rng(7)
+    for case in range(16):
+        H, W = int(rng.integers(40, 300)), int(rng.integers(40, 400))
+        if case % 5 == 0:
+            W = W // 4 * 4 + int(rng.integers(1, 4))
+        labels, depth, P = O.synthetic_scene(H, W, 500 + case)
+        kind = case % 4
+        mask = [(labels == 1), (labels >= 1), (labels == 1) | (rng.random((H, W)) > 0.995),
+                (labels == 2) | (labels == 3)][kind].astype(np.uint8)
+        _compare_maps(sel, mask, depth, P)
