@@ -476,6 +476,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     gaussian1d(a.k1);
+    a.no_skip = getenv("LG_NO_SKIP") ? 1 : 0;
     a.nt_stores = getenv("LG_NT_STORES") ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
         ProfScope ps(h, "final", s, true);

@@ -51,6 +51,7 @@ struct LgFinalArgs {
     float min_edge_distance, stem_valid_thresh;
     float inv_maxd;
     float k1[5];  // separable 1-D Gaussian (size 5, sigma 5/6)
+    int no_skip;    // 1: disable the off-mask fast path (LG_NO_SKIP=1, A/B measurements)
     int nt_stores;  // 0: plain stores (default); 1: non-temporal plane stores (LG_NT_STORES=1; measured slower)
 };
 

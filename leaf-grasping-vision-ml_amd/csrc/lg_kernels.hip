@@ -673,37 +673,47 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
             const float ramp = a.iso_ramp_top + ramp_step * (float)y;
             float o_sdf[4], o_app[4], o_flat[4], o_iso[4], o_acc[4], o_stem[4], o_trad[4];
             uint32_t vbytes = 0;
+            // A leaf covers a few per cent of a frame: when no lane of this wave sits on the mask every plane but
+            // flatness is exactly zero (they are all "* mask"), traditional = w_flat * flatness and nothing is
+            // valid.  The wave-uniform branch skips the geometry / SDF / isolation arithmetic for those rows.
+            const bool wave_on_mask = a.no_skip || __ballot(mnib != 0) != 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = x0 + j;
-                const float m = ((mnib >> j) & 1u) ? 1.0f : 0.0f;
-                const float st = ((snib >> j) & 1u) ? 1.0f : 0.0f;
                 // flatness: Sobel cross-correlation on the smoothed plane, exp(-5 |grad|)   (:646-655)
                 float sx = (ga[j + 2] - ga[j]) + 2.0f * (gb[j + 2] - gb[j]) + (gc[j + 2] - gc[j]);
                 float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
                 float flat = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(sx * sx + sy * sy));  // v_sqrt_f32, 1 ulp
-                // closed-form geometry planes                                           (:502-524, :569-593)
-                const float dxp = (float)(x - a.cxi) - a.cxf;
-                const float r2 = dxp * dxp + dyp * dyp;
-                const float inv_r = r2 > 0.0f ? rsqrtf(r2) : 0.0f;
-                const float r = r2 * inv_r;
-                const float app = a.f * rsqrtf(r2 + f2) * m;
-                const float cosang = r2 > 0.0f ? dxp * inv_r : 1.0f;
-                const float acc = (a.access_w_dist * (1.0f - r * a.inv_maxd) + a.access_w_dir * cosang) * m;
-                // SDF / edge term                                                        (:526-567)
-                const float align = fp.has_angle ? fabsf(dxp * inv_r * fp.sin_t - dyp * inv_r * fp.cos_t) : 1.0f;
-                const float dd = din[j] - a.optimal_distance;
-                const float interior = __expf(-(dd * dd) * inv_2s2);
-                const float sdfn = din[j] * inv_maxabs;  // inside the mask d_out == 0
-                const float sdf = (a.sdf_w_interior * interior + a.sdf_w_align * align + a.sdf_w_sdf * sdfn) * m;
-                // degenerate isolation map: chamfer-3 transform of an image with no zero pixel (:595-633)
-                const int dbrd = min(min(x + 1, W - x), dyb);
-                const float dt3 = (float)(LG_INIT0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
-                const float s = dt3 * a.iso_inv_max;
-                const float iso = (a.iso_w_close * s + a.iso_w_wide * s) * ramp * m;
-                // fusion + validity                                                      (:272-288)
-                const float trad = (a.w_approach * app + a.w_sdf * sdf + a.w_flat * flat + a.w_access * acc) * (1.0f - st);
-                const bool valid = (din[j] > a.min_edge_distance) && (m > 0.0f) && (st < a.stem_valid_thresh);
+                float sdf = 0.0f, app = 0.0f, acc = 0.0f, iso = 0.0f, st = 0.0f, trad;
+                bool valid = false;
+                if (wave_on_mask) {
+                    const float m = ((mnib >> j) & 1u) ? 1.0f : 0.0f;
+                    st = ((snib >> j) & 1u) ? 1.0f : 0.0f;
+                    // closed-form geometry planes                                           (:502-524, :569-593)
+                    const float dxp = (float)(x - a.cxi) - a.cxf;
+                    const float r2 = dxp * dxp + dyp * dyp;
+                    const float inv_r = r2 > 0.0f ? rsqrtf(r2) : 0.0f;
+                    const float r = r2 * inv_r;
+                    app = a.f * rsqrtf(r2 + f2) * m;
+                    const float cosang = r2 > 0.0f ? dxp * inv_r : 1.0f;
+                    acc = (a.access_w_dist * (1.0f - r * a.inv_maxd) + a.access_w_dir * cosang) * m;
+                    // SDF / edge term                                                        (:526-567)
+                    const float align = fp.has_angle ? fabsf(dxp * inv_r * fp.sin_t - dyp * inv_r * fp.cos_t) : 1.0f;
+                    const float dd = din[j] - a.optimal_distance;
+                    const float interior = __expf(-(dd * dd) * inv_2s2);
+                    const float sdfn = din[j] * inv_maxabs;  // inside the mask d_out == 0
+                    sdf = (a.sdf_w_interior * interior + a.sdf_w_align * align + a.sdf_w_sdf * sdfn) * m;
+                    // degenerate isolation map: chamfer-3 transform of an image with no zero pixel (:595-633)
+                    const int dbrd = min(min(x + 1, W - x), dyb);
+                    const float dt3 = (float)(LG_INIT0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
+                    const float s = dt3 * a.iso_inv_max;
+                    iso = (a.iso_w_close * s + a.iso_w_wide * s) * ramp * m;
+                    // fusion + validity                                                      (:272-288)
+                    trad = (a.w_approach * app + a.w_sdf * sdf + a.w_flat * flat + a.w_access * acc) * (1.0f - st);
+                    valid = (din[j] > a.min_edge_distance) && (m > 0.0f) && (st < a.stem_valid_thresh);
+                } else {
+                    trad = a.w_flat * flat;  // (0.4*0 + 0.3*0 + 0.2*flat + 0.1*0) * (1 - 0), same float32 operations' result
+                }
                 o_sdf[j] = sdf; o_app[j] = app; o_flat[j] = flat; o_iso[j] = iso; o_acc[j] = acc; o_stem[j] = st;
                 o_trad[j] = trad;
                 if (valid) vbytes |= 1u << (8 * j);
