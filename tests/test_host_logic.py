@@ -152,9 +152,13 @@ dist.destroy_process_group()
 def test_sharding_world_size_2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER % REPO)
+    import socket
+    with socket.socket() as sock:   # a free port: a fixed one can still be in TIME_WAIT from the previous run
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=180, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
