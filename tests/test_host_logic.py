@@ -144,7 +144,7 @@ allr = gather_results(local, 7, rank, world, dist)
 assert [r[1] for r in allr] == list(range(7)), allr
 assert all(r[2] == r[1] %% world for r in allr)
 assert elapsed >= 0.1 - 1e-3, elapsed
-print("rank", rank, "ok", round(elapsed, 3))
+os.write(1, f"rank{rank}ok {elapsed:.3f}\n".encode())   # one write: ranks share the pipe
 dist.destroy_process_group()
 """
 
@@ -161,4 +161,4 @@ def test_sharding_world_size_2_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=180, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert "rank0ok" in out.stdout and "rank1ok" in out.stdout
