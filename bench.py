@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 #   read depth f32 4 + distance_map f32 4 + mask bits 1/8 + stem bits 1/8; write 7 f32 planes 28 + valid u8 1
 FINAL_BYTES_PER_PX = 4 + 4 + 0.125 + 0.125 + 28 + 1
 PATH_BYTES_PER_PX = 38.0  # whole-path compulsory traffic per pixel
+BASELINE_METRIC = "frames/sec (1080p depth+mask) grasp scoring, 1/8 MI355X; % HBM roofline"  # BASELINE.json:metric
 CPU_BASELINE_THREADS = 16  # one GPU's share of the box's host cores (torch intra-op threads of the CPU leg)
 
 
@@ -193,7 +194,7 @@ def main():
         fps = frames / elapsed
         px = B * H * W
         out = {
-            "metric": "frames/sec (1080p depth+mask) grasp scoring",
+            "metric": BASELINE_METRIC,
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": world,
