@@ -17,7 +17,9 @@
 
 // ---- final-kernel tile
 #define LG_TW 64
-#define LG_TH 32
+#ifndef LG_TH
+#define LG_TH 16   // measured at 1080p B=128: 16 -> 1.78 ms (0.69 of HBM peak), 32 -> 1.86 ms, 64 -> 2.11 ms
+#endif
 
 struct LgFrameParams {  // per frame, written by the host after contour analysis
     float sin_t, cos_t;

@@ -503,7 +503,7 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
 // ============================================================================ fused score planes
 // One pass producing sdf_score, approach, flatness, isolation, accessibility, stem, traditional and the
 // validity mask (grasp_point_selector.py:256-288) from depth + mask bits + distance_map (+ frame scalars).
-// Tile 64x32, 256 threads, each thread 4 consecutive pixels x 2 rows (16-byte stores per lane).
+// Tile 64 x LG_TH (16), 256 threads, each thread 4 consecutive pixels x LG_TH/16 rows (16-byte stores per lane).
 __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     constexpr int DW = 72;             // dm tile: cols tx0-4 .. tx0+67
     constexpr int DH = LG_TH + 6;      // rows ty0-3 .. ty0+34
@@ -538,10 +538,12 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const int txi = t & 15, tyi = t >> 4;
     const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
     const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
-    float din_pre[2][4];
-    unsigned mnib_pre[2], snib_pre[2];
+    constexpr int RPT = LG_TH / 16;   // rows per thread (16 thread rows per tile)
+    static_assert(LG_TH % 16 == 0 && RPT >= 1, "tile height must be a multiple of 16");
+    float din_pre[RPT][4];
+    unsigned mnib_pre[RPT], snib_pre[RPT];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
+    for (int rr = 0; rr < RPT; rr++) {
         const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
         mnib_pre[rr] = snib_pre[rr] = 0;
 #pragma unroll
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const float ramp_step = (H > 1) ? (a.iso_ramp_bottom - a.iso_ramp_top) / (float)(H - 1) : 0.0f;
     unsigned long long best = 0;
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
+    for (int rr = 0; rr < RPT; rr++) {
         const int ly = tyi + 16 * rr;
         const int y = ty0 + ly;
         const int x0 = tx0 + 4 * txi;
