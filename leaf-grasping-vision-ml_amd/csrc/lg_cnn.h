@@ -12,6 +12,7 @@ struct LgCnn {
     bool loaded = false;
     float* wconv[6] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded
     float* bconv[6] = {nullptr};
+    float* uwino[6] = {nullptr};  // Winograd F(2x2,3x3) weights [cin][cout][16] (layers 1..5)
     float* att_w = nullptr;       // [256]
     float att_b = 0.f;
     float* fcw[4] = {nullptr};    // transposed [in][out], BN folded (first three)

@@ -9,6 +9,7 @@
 #include "lg_cnn.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -185,6 +186,200 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) form of the same 3x3 convolutions (layers 1..5; layer 0 has 9 input channels and stays
+// direct):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input tile d / 2x2 output tile Y, i.e. 16 independent
+// contractions over the input channels instead of 36 multiply-adds per output pair: 2.25x fewer MFMA flops,
+// still exact-f32 products and f32 accumulation (v_mfma_f32_16x16x4_f32).
+//
+// Workgroup = 256 threads = 32 tiles x 64 output channels x all 16 Winograd positions.  Wave w owns output
+// channels 16w..16w+15: M = 16 channels, N = 16 tiles, K = 4 input channels per MFMA, 16 positions x 2 tile
+// halves = 32 accumulators (128 VGPRs).  Every lane therefore ends with all 16 positions of its (channel,
+// tile) pairs in its own registers and the output transform + bias + ReLU (+ the 2x2 max-pool, which is
+// exactly one output tile) needs no exchange.
+//   * A operand  U[ci][co][16]: 64 contiguous bytes per lane straight from L2 into registers (each element is
+//     used by one wave only, LDS would add nothing); next k-step prefetched during the current one.
+//   * B operand  V[ci][tile][16 (+4 pad)]: input chunk of 8 channels streamed by global_load_lds into a 2-stage
+//     LDS ring, transformed by thread (ci, tile) = (t>>5, t&31) with 8 ds_read_b64 + 32 adds + 4 ds_write_b128,
+//     read back as 4 ds_read_b128 per tile half (row stride 80 B: conflict free).
+template <int CIN, int COUT, int WI, bool POOL>
+__global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int N, int ntb) {
+    constexpr int KC = 8;                                  // input channels per chunk (2 MFMA k-steps)
+    constexpr int TC = WI / 2, TP = TC * TC;               // tile columns, tiles per patch
+    constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup (8x8 images: 2)
+    constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // workgroups (row bands) per patch
+    constexpr int TPB = 32 / PB;                           // tiles of one patch inside the workgroup
+    constexpr int TROWS = TPB / TC;                        // tile rows per band
+    constexpr int RH = 2 * TROWS + 2, RW = WI + 2;         // staged input region (halo 1) per channel and patch
+    constexpr int RS = RH * RW, S = PB * RS;
+    constexpr int NIN = (KC * S + 255) / 256;
+    constexpr int VS = 20;                                 // floats per (ci, tile) row of V: 16 positions + 4 pad
+    constexpr int NCB = COUT / 64;
+    constexpr int NC = CIN / KC;
+    static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (RW % 2) == 0 && (RS % 2) == 0, "shape");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * NIN * 256 + KC * 32 * VS];
+    float* const s_v = s_mem + 2 * NIN * 256;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // XCD-aware order: an XCD walks consecutive (tile block, channel block) pairs, so the NCB workgroups that
+    // share an input band run back to back on one L2.
+    long long id = blockIdx.x;
+    {
+        const long long total = (long long)ntb * NCB, q = total / 8, r = total % 8;
+        const long long xcd = id % 8, j = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tb = (int)(id / NCB), cb = (int)(id % NCB);
+    const int n0 = PB > 1 ? tb * PB : tb / BPP;
+    const int band = PB > 1 ? 0 : tb % BPP;
+    const int y0 = band * 2 * TROWS;                       // first output row of the band
+    const int co0 = cb * 64;
+
+    // ---- input staging offsets (chunk invariant)
+    int off_in[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int e = t + 256 * j;
+        const int ci = e / S, r = e % S;
+        const int pb = r / RS, r2 = r % RS;
+        const int ry = r2 / RW, rx = r2 % RW;
+        const int gy = y0 - 1 + ry, gx = rx - 1;
+        const bool ok = e < KC * S && gy >= 0 && gy < WI && gx >= 0 && gx < WI && n0 + pb < N;
+        off_in[j] = ok ? ((pb * CIN + ci) * WI + gy) * WI + gx : -1;
+    }
+    const float* in_n = in + (size_t)n0 * CIN * WI * WI;
+    auto issue_input = [&](int c, int stage) {
+        const float* in_c = in_n + (size_t)c * KC * WI * WI;
+        float* sb = s_mem + stage * (NIN * 256);
+#pragma unroll
+        for (int j = 0; j < NIN; j++) {
+            const float* src = off_in[j] >= 0 ? in_c + off_in[j] : lg_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
+        }
+    };
+    // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co]
+    const float* u_lane = U + ((size_t)(lane >> 4) * COUT + co0 + 16 * wave + (lane & 15)) * 16;
+    auto load_u = [&](int ks, f32x4 (&a)[4]) {             // ks = global k-step (4 input channels each)
+        const f32x4* p = reinterpret_cast<const f32x4*>(u_lane + (size_t)ks * 4 * COUT * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) a[q] = p[q];
+    };
+    // ---- transform role: (channel of the chunk, tile)
+    const int tci = t >> 5, tau = t & 31;
+    const int tpb = tau / TPB, ttl = tau % TPB;
+    const int ttr = ttl / TC, ttc = ttl % TC;
+    const int tsrc = tci * S + tpb * RS + (2 * ttr) * RW + 2 * ttc;
+    float* const tdst = s_v + (tci * 32 + tau) * VS;
+    const float* const vsrc = s_v + ((lane >> 4) * 32 + (lane & 15)) * VS;
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; p++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) acc[p][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // one k-step = 32 MFMAs; `mid` runs after the first 8 (i.e. after the wait for this step's A operand, so a
+    // prefetch issued there is not caught by that wait)
+    auto mfma_step = [&](int ksl, const f32x4 (&a)[4], auto&& mid) {   // ksl = k-step inside the chunk
+        const float* vb = vsrc + ksl * 4 * 32 * VS;
+        f32x4 b0[4], b1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            b0[q] = *reinterpret_cast<const f32x4*>(vb + 4 * q);
+            b1[q] = *reinterpret_cast<const f32x4*>(vb + 16 * VS + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[4 * q + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][e], b0[q][e], acc[4 * q + e][0], 0, 0, 0);
+                acc[4 * q + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][e], b1[q][e], acc[4 * q + e][1], 0, 0, 0);
+            }
+            if (q == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    f32x4 a0[4], a1[4];
+    issue_input(0, 0);
+    load_u(0, a0);
+#pragma unroll 1
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();                                   // vmcnt(0): input(c) + a0 landed; V / other stage free
+        load_u(2 * c + 1, a1);
+        if (c + 1 < NC) issue_input(c + 1, (c + 1) & 1);
+        {   // V = B^T d B for (tci, tau)
+            const float* sp = s_mem + (c & 1) * (NIN * 256) + tsrc;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // plain float reads (merged into ds_read2_b64): a float2-typed read makes hipcc drain vmcnt, i.e. the
+                // next chunk's global_load_lds prefetch, in front of it
+                d[i][0] = sp[i * RW]; d[i][1] = sp[i * RW + 1]; d[i][2] = sp[i * RW + 2]; d[i][3] = sp[i * RW + 3];
+            }
+            float r[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                r[0][j] = d[0][j] - d[2][j];
+                r[1][j] = d[1][j] + d[2][j];
+                r[2][j] = d[2][j] - d[1][j];
+                r[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f32x4 v = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
+                *reinterpret_cast<f32x4*>(tdst + 4 * i) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V visible; does not drain the prefetches
+        mfma_step(0, a0, [] {});
+        // prefetch of the next chunk's first k-step, pinned behind the first MFMAs of this one: hipcc waits with
+        // vmcnt(0) for a1, and sinks an unpinned prefetch to the loop end where the barrier's vmcnt(0) exposes it
+        mfma_step(1, a1, [&] { load_u(2 * c + 2 < 2 * NC ? 2 * c + 2 : 2 * NC - 1, a0); });
+    }
+
+    // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile), planar NCHW store
+    constexpr int WO = POOL ? WI / 2 : WI;
+    const int etau0 = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int etau = 16 * h + etau0;
+        const int epb = etau / TPB, etl = etau % TPB;
+        const int n = n0 + epb;
+        const int trg = band * TROWS + etl / TC, tcg = etl % TC;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int co = co0 + 16 * wave + 4 * (lane >> 4) + r;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float m0 = acc[j][h][r], m1 = acc[4 + j][h][r], m2 = acc[8 + j][h][r], m3 = acc[12 + j][h][r];
+                s0[j] = m0 + m1 + m2;
+                s1[j] = m1 - m2 - m3;
+            }
+            const float bv = bias[co];
+            const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+            const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+            if (n < N) {
+                float* o = out + (size_t)n * COUT * WO * WO + (size_t)co * WO * WO;
+                if (POOL) {
+                    o[trg * WO + tcg] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)), 0.0f);
+                } else {
+                    *reinterpret_cast<float2*>(o + (2 * trg) * WO + 2 * tcg) = make_float2(fmaxf(y00, 0.f), fmaxf(y01, 0.f));
+                    *reinterpret_cast<float2*>(o + (2 * trg + 1) * WO + 2 * tcg) = make_float2(fmaxf(y10, 0.f), fmaxf(y11, 0.f));
+                }
+            }
+        }
+    }
+}
+
 // attention (1x1 conv 256->1 + sigmoid), global average pool, classifier 256->256->128->64->1 (BN folded).
 // model.py:32-36,63-84,108-128.  One workgroup per patch.
 __global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, const float* __restrict__ att_w,
@@ -259,11 +454,21 @@ void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t
                        s, in, c->wconv[L], c->bconv[L], out);
 }
 
+template <int L>
+void launch_wino(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
+    constexpr LayerCfg cfg = kLayers[L];
+    constexpr int TP = (cfg.wi / 2) * (cfg.wi / 2);
+    const int ntb = TP >= 32 ? N * (TP / 32) : (N + 32 / TP - 1) / (32 / TP);
+    const int grid = ntb * (cfg.cout / 64);
+    hipLaunchKernelGGL((lg_wino_kernel<cfg.cin, cfg.cout, cfg.wi, cfg.pool>), dim3(grid), dim3(256), 0, s, in, c->uwino[L],
+                       c->bconv[L], out, N, ntb);
+}
+
 }  // namespace
 
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
-    for (int i = 0; i < 6; i++) { F(c->wconv[i]); F(c->bconv[i]); }
+    for (int i = 0; i < 6; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); }
     F(c->att_w);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
     F(c->act[0]); F(c->act[1]);
@@ -303,6 +508,33 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
         if (rc) return rc;
         rc = upload(&c->bconv[L], bp, err);
         if (rc) return rc;
+        if (L >= 1) {
+            // Winograd-domain weights U = G g G^T of the BN-folded kernel, layout [ci][co][4i+j], rounded once from double
+            std::vector<float> uw((size_t)cfg.cin * cfg.cout * 16);
+            for (int co = 0; co < cfg.cout; co++) {
+                const double sc = (double)w->bn_g[L][co] / sqrt((double)w->bn_v[L][co] + (double)eps);
+                for (int ci = 0; ci < cfg.cin; ci++) {
+                    double g[3][3], gg[4][3];
+                    for (int tap = 0; tap < 9; tap++)
+                        g[tap / 3][tap % 3] = (double)w->conv_w[L][((size_t)co * cfg.cin + ci) * 9 + tap] * sc;
+                    for (int j = 0; j < 3; j++) {
+                        gg[0][j] = g[0][j];
+                        gg[1][j] = 0.5 * (g[0][j] + g[1][j] + g[2][j]);
+                        gg[2][j] = 0.5 * (g[0][j] - g[1][j] + g[2][j]);
+                        gg[3][j] = g[2][j];
+                    }
+                    float* u = &uw[((size_t)ci * cfg.cout + co) * 16];
+                    for (int i = 0; i < 4; i++) {
+                        u[4 * i + 0] = (float)gg[i][0];
+                        u[4 * i + 1] = (float)(0.5 * (gg[i][0] + gg[i][1] + gg[i][2]));
+                        u[4 * i + 2] = (float)(0.5 * (gg[i][0] - gg[i][1] + gg[i][2]));
+                        u[4 * i + 3] = (float)gg[i][2];
+                    }
+                }
+            }
+            rc = upload(&c->uwino[L], uw, err);
+            if (rc) return rc;
+        }
     }
     if (!w->att_w || !w->att_b) { *err = "lg_cnn_load: missing attention tensor"; return LG_ERR_INVALID; }
     {
@@ -357,11 +589,16 @@ int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t
     float *A = c->act[0], *B = c->act[1];
     //            L  KC PP CP
     launch_conv<0, 10, 4, 1>(patches, c, A, N, s);   // 9 -> 64, 32x32
-    launch_conv<1, 8, 4, 1>(A, c, B, N, s);          // 64 -> 64, pool -> 16x16
-    launch_conv<2, 8, 4, 1>(B, c, A, N, s);          // 64 -> 128, 16x16
-    launch_conv<3, 8, 4, 1>(A, c, B, N, s);          // 128 -> 128, pool -> 8x8
-    launch_conv<4, 4, 1, 4>(B, c, A, N, s);          // 128 -> 256, 8x8
-    launch_conv<5, 4, 1, 4>(A, c, B, N, s);          // 256 -> 256, pool -> 4x4
+    // Winograd F(2x2,3x3) for layers 1..5 (2.25x fewer MFMA flops); LG_CNN_DIRECT=1 selects the direct implicit GEMM
+    // for all layers, LG_CNN_WINO_MASK=<bits> a per-layer choice (bit L = layer L on Winograd) -- A/B and test switches,
+    // read per call.
+    int wmask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
+    if (const char* e = getenv("LG_CNN_WINO_MASK")) wmask = atoi(e) & 0x3e;
+    if (wmask & 2) launch_wino<1>(A, c, B, N, s); else launch_conv<1, 8, 4, 1>(A, c, B, N, s);   // 64 -> 64, pool -> 16x16
+    if (wmask & 4) launch_wino<2>(B, c, A, N, s); else launch_conv<2, 8, 4, 1>(B, c, A, N, s);   // 64 -> 128, 16x16
+    if (wmask & 8) launch_wino<3>(A, c, B, N, s); else launch_conv<3, 8, 4, 1>(A, c, B, N, s);   // 128 -> 128, pool -> 8x8
+    if (wmask & 16) launch_wino<4>(B, c, A, N, s); else launch_conv<4, 4, 1, 4>(B, c, A, N, s);  // 128 -> 256, 8x8
+    if (wmask & 32) launch_wino<5>(A, c, B, N, s); else launch_conv<5, 4, 1, 4>(A, c, B, N, s);  // 256 -> 256, pool -> 4x4
     hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_w, c->att_b, c->fcw[0], c->fcb[0], c->fcw[1],
                        c->fcb[1], c->fcw[2], c->fcb[2], c->fcw[3], c->fcb[3], logits);
     return LG_OK;

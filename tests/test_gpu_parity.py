@@ -195,6 +195,26 @@ def test_cnn_vs_reference_golden(sel, golden):
     sel.clear_cnn()
 
 
+def test_cnn_winograd_matches_direct(sel, monkeypatch):
+    """Winograd F(2x2,3x3) conv layers (default) vs the direct implicit-GEMM kernels, layer by layer and all together,
+    for even / odd / single patch counts (8x8 layers put two patches in one workgroup)."""
+    params = O.cnn_closed_form_params(seed=0)
+    sel.set_cnn_state_dict(params)
+    x = torch.from_numpy(O.synthetic_patches(41, seed=5)).cuda()
+    monkeypatch.setenv("LG_CNN_DIRECT", "1")
+    want = sel.cnn_forward(x).cpu().numpy()
+    monkeypatch.delenv("LG_CNN_DIRECT")
+    for mask in (2, 4, 8, 16, 32, 0x3e):
+        monkeypatch.setenv("LG_CNN_WINO_MASK", str(mask))
+        got = sel.cnn_forward(x).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=f"wino mask {mask}")
+        for n in (1, 2, 7):
+            np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), got[:n], err_msg=f"mask {mask} n {n}")
+    monkeypatch.delenv("LG_CNN_WINO_MASK")
+    np.testing.assert_allclose(sel.cnn_forward(x).cpu().numpy(), O.cnn_forward(params, x.cpu().numpy()), rtol=1e-4, atol=1e-5)
+    sel.clear_cnn()
+
+
 def test_ml_score_golden(sel, golden):
     sel.set_camera_params(golden["P"])
     sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
