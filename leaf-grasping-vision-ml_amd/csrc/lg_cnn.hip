@@ -12,9 +12,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef LG_WS_EXP
+#define LG_WS_EXP 0   // timing ablations of lg_wino_ws_kernel (wrong results!): 1 no A loads, 2 no B reads, 4 no transform, 8 no input
+#endif
 
 __device__ float lg_zero_pad[4];  // zero-initialised source for padded / out-of-range direct-to-LDS lanes
 
@@ -380,6 +385,247 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the Winograd layer (LG_CNN_WS_KC=8; measured SLOWER than the lock-step kernel above, kept
+// as the documented experiment with its ablation switches).  The kernel above alternates "transform a
+// chunk" and "64 MFMAs" in every wave, so the matrix pipe idles whenever both workgroups of a CU transform or
+// wait at a barrier together (measured 0.57-0.60 of the f32 MFMA peak).  Here a persistent workgroup of 512
+// threads per CU is split by role:
+//   waves 4..7 (producers): stream the input chunks by global_load_lds and write V = B^T d B into a 2-stage LDS ring,
+//                           one chunk ahead of the consumers, across work-item boundaries;
+//   waves 0..3 (consumers): nothing but operand fetches and MFMAs (16 output channels x 32 tiles x 16 positions
+//                           each, as above), B operands of the next half k-step requested before the MFMAs of the
+//                           current one, A operands of the next k-step prefetched from L2;
+// one s_barrier per chunk hands a V stage over (consumers arrive with an LDS-only wait, so their A prefetch stays
+// in flight).  A work item = (32-tile block, 64-channel block); a workgroup takes a contiguous range of items, so the
+// channel blocks of one input band follow each other on one CU (input band hot in L2) and prologue / epilogue
+// latencies are paid once per workgroup / overlapped by the producers' run-ahead.
+template <int CIN, int COUT, int WI, bool POOL, int KC>
+__global__ __launch_bounds__(512, 1) void lg_wino_ws_kernel(const float* __restrict__ in, const float* __restrict__ U,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int N, int ntb) {
+    constexpr int TC = WI / 2, TP = TC * TC;
+    constexpr int PB = TP >= 32 ? 1 : 32 / TP;
+    constexpr int BPP = TP >= 32 ? TP / 32 : 1;
+    constexpr int TPB = 32 / PB;
+    constexpr int TROWS = TPB / TC;
+    constexpr int RH = 2 * TROWS + 2, RW = WI + 2;
+    constexpr int RS = RH * RW, S = PB * RS;
+    constexpr int NIN = (KC * S + 255) / 256;
+    constexpr int INB = NIN * 256;                         // floats per input stage
+    constexpr int VS = 20;
+    constexpr int VB = KC * 32 * VS;                       // floats per V stage
+    constexpr int NCB = COUT / 64;
+    constexpr int NC = CIN / KC;                           // chunks per work item
+    constexpr int KS = KC / 4;                             // MFMA k-steps per chunk
+    static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (KS % 2) == 0 && KC % 8 == 0, "shape");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int RI = 3;                                  // input ring: chunks sq+2, sq+3 in flight while sq+1 is transformed
+    __shared__ __attribute__((aligned(16))) float s_mem[RI * INB + 2 * VB];
+    float* const s_v = s_mem + RI * INB;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const long long total = (long long)ntb * NCB;
+    const int it0 = (int)(total * blockIdx.x / gridDim.x), it1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int nitems = it1 - it0;
+    if (nitems <= 0) return;
+    const int nseq = nitems * NC;                          // chunks this workgroup streams
+
+    if (wave >= 4) {
+        // ================================================================= producers
+        const int pt = t - 256, pw = wave - 4;
+        int off_in[NIN];
+        const float* in_n = in;
+        auto issue = [&](int sq) {
+            const int c = sq % NC;
+            if (c == 0) {                                  // new work item: staging offsets of its band
+                const int tb = (it0 + sq / NC) / NCB;
+                const int n0 = PB > 1 ? tb * PB : tb / BPP;
+                const int y0 = (PB > 1 ? 0 : tb % BPP) * 2 * TROWS;
+#pragma unroll
+                for (int j = 0; j < NIN; j++) {
+                    const int e = pt + 256 * j;
+                    const int ci = e / S, r = e % S;
+                    const int pb = r / RS, r2 = r % RS;
+                    const int ry = r2 / RW, rx = r2 % RW;
+                    const int gy = y0 - 1 + ry, gx = rx - 1;
+                    const bool ok = e < KC * S && gy >= 0 && gy < WI && gx >= 0 && gx < WI && n0 + pb < N;
+                    off_in[j] = ok ? ((pb * CIN + ci) * WI + gy) * WI + gx : -1;
+                }
+                in_n = in + (size_t)n0 * CIN * WI * WI;
+            }
+            const float* in_c = in_n + (size_t)c * KC * WI * WI;
+            float* sb = s_mem + (sq % RI) * INB;
+#pragma unroll
+            for (int j = 0; j < NIN; j++) {
+                const float* src = off_in[j] >= 0 ? in_c + off_in[j] : lg_zero_pad;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * pw), 4, 0, 0);
+            }
+        };
+        const int tau = pt & 31;
+        const int tpb = tau / TPB, ttl = tau % TPB;
+        const int tsrc0 = tpb * RS + (2 * (ttl / TC)) * RW + 2 * (ttl % TC);
+        auto transform = [&](int sq) {                     // V = B^T d B for (channel, tile) = (pt >> 5 [+8], pt & 31)
+#pragma unroll
+            for (int it = 0; it < KC / 8; it++) {
+                const int tci = (pt >> 5) + 8 * it;
+                const float* sp = s_mem + (sq % RI) * INB + tci * S + tsrc0;
+                float d[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {              // plain float reads (see lg_wino_kernel)
+                    d[i][0] = sp[i * RW]; d[i][1] = sp[i * RW + 1]; d[i][2] = sp[i * RW + 2]; d[i][3] = sp[i * RW + 3];
+                }
+                float r[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    r[0][j] = d[0][j] - d[2][j];
+                    r[1][j] = d[1][j] + d[2][j];
+                    r[2][j] = d[2][j] - d[1][j];
+                    r[3][j] = d[1][j] - d[3][j];
+                }
+                float* dst = s_v + (sq & 1) * VB + (tci * 32 + tau) * VS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    f32x4 v = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
+                    *reinterpret_cast<f32x4*>(dst + 4 * i) = v;
+                }
+            }
+        };
+        // HBM latency (2-3 us) exceeds one chunk of MFMA time (~1 us): the input runs two chunks ahead of the transform.
+        // Loads return in order, so "at most NIN outstanding" = everything but the newest chunk has landed.
+        issue(0);
+        if (1 < nseq) issue(1);
+        if (2 < nseq) {
+            issue(2);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NIN) : "memory");   // input(0) visible
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        transform(0);
+        if (2 < nseq) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");  // V(0), input(1)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+        for (int sq = 0; sq < nseq; sq++) {                // consumers work on V(sq)
+            const bool more_in = sq + 3 < nseq;
+            if (more_in && !(LG_WS_EXP & 8)) issue(sq + 3);   // stage sq % 3: its last reader was transform(sq)
+            if (sq + 1 < nseq && !(LG_WS_EXP & 4)) transform(sq + 1);          // V stage (sq+1) & 1: its last readers were the MFMAs of sq-1
+            if (more_in) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");  // input(sq+2) landed
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+        // ================================================================= consumers
+        const float* const vsrc = s_v + ((lane >> 4) * 32 + (lane & 15)) * VS;
+        const float* const u_lane = U + ((size_t)(lane >> 4) * COUT + 16 * wave + (lane & 15)) * 16;
+        f32x4 acc[16][2];
+        f32x4 ab[2][4];                                    // A operand ring (k-step parity)
+        f32x4 bb[2][4];                                    // B operand ring (half k-step parity)
+        auto load_u = [&](int cb, int ks, f32x4 (&a)[4]) { // ks = k-step inside the item (4 input channels each)
+            const f32x4* p = reinterpret_cast<const f32x4*>(u_lane + ((size_t)ks * 4 * COUT + cb * 64) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = p[q];
+        };
+        auto load_b = [&](int stage, int ksl, int h, f32x4 (&b)[4]) {
+            const float* vb = vsrc + stage * VB + (ksl * 4 * 32 + 16 * h) * VS;
+#pragma unroll
+            for (int q = 0; q < 4; q++) b[q] = *reinterpret_cast<const f32x4*>(vb + 4 * q);
+        };
+        // one chunk: KS k-steps x 2 tile halves; `first` zero-initialises the accumulators with the first k-step
+        auto chunk = [&](auto first_tag, int stage, int cb, int c, int cb_next, bool more) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            load_b(stage, 0, 0, bb[0]);
+            if (LG_WS_EXP & 2) load_b(stage, 0, 1, bb[1]);
+#pragma unroll
+            for (int ksl = 0; ksl < KS; ksl++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int u = 2 * ksl + h;
+                    if (u + 1 < 2 * KS && !(LG_WS_EXP & 2)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_b(stage, (u + 1) >> 1, (u + 1) & 1, bb[(u + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (FIRST && ksl == 0)
+                                acc[4 * q + e][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    ab[ksl & 1][q][e], bb[u & 1][q][e], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            else
+                                acc[4 * q + e][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[ksl & 1][q][e], bb[u & 1][q][e],
+                                                                                           acc[4 * q + e][h], 0, 0, 0);
+                        }
+                        if (q == 0 && h == 0) {
+                            // A operand of the next k-step (next chunk / next item at the end), behind the wait for
+                            // this step's A so that wait cannot catch it
+                            __builtin_amdgcn_sched_barrier(0);
+                            // (unconditional, clamped at the very end: a branch here makes hipcc wait vmcnt(0) at the join)
+                            const int ksn = c * KS + ksl + 1;
+                            const bool within = ksn < NC * KS;
+                            if (!(LG_WS_EXP & 1)) load_u(within || !more ? cb : cb_next, within ? ksn : 0, ab[(ksl + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done with this V stage
+        };
+
+        load_u(it0 % NCB, 0, ab[0]);
+        if (LG_WS_EXP & 1) load_u(it0 % NCB, 1, ab[1]);
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        constexpr int WO = POOL ? WI / 2 : WI;
+        int sq = 0;
+#pragma unroll 1
+        for (int item = it0; item < it1; item++) {
+            const int tb = item / NCB, cb = item % NCB;
+            const int cb_next = (item + 1) % NCB;
+            const bool more = item + 1 < it1;
+            const int co_l = cb * 64 + 16 * wave + 4 * (lane >> 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co_l);
+            chunk(std::true_type{}, sq & 1, cb, 0, cb_next, more);
+            sq++;
+#pragma unroll 1
+            for (int c = 1; c < NC; c++, sq++) chunk(std::false_type{}, sq & 1, cb, c, cb_next, more);
+
+            // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile), planar NCHW store
+            const int n0 = PB > 1 ? tb * PB : tb / BPP;
+            const int band = PB > 1 ? 0 : tb % BPP;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int etau = 16 * h + (lane & 15);
+                const int epb = etau / TPB, etl = etau % TPB;
+                const int n = n0 + epb;
+                const int trg = band * TROWS + etl / TC, tcg = etl % TC;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float s0[4], s1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float m0 = acc[j][h][r], m1 = acc[4 + j][h][r], m2 = acc[8 + j][h][r], m3 = acc[12 + j][h][r];
+                        s0[j] = m0 + m1 + m2;
+                        s1[j] = m1 - m2 - m3;
+                    }
+                    const float y00 = s0[0] + s0[1] + s0[2] + bv[r], y01 = s0[1] - s0[2] - s0[3] + bv[r];
+                    const float y10 = s1[0] + s1[1] + s1[2] + bv[r], y11 = s1[1] - s1[2] - s1[3] + bv[r];
+                    if (n < N) {
+                        float* o = out + (size_t)n * COUT * WO * WO + (size_t)(co_l + r) * WO * WO;
+                        if (POOL) {
+                            o[trg * WO + tcg] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)), 0.0f);
+                        } else {
+                            *reinterpret_cast<float2*>(o + (2 * trg) * WO + 2 * tcg) = make_float2(fmaxf(y00, 0.f), fmaxf(y01, 0.f));
+                            *reinterpret_cast<float2*>(o + (2 * trg + 1) * WO + 2 * tcg) = make_float2(fmaxf(y10, 0.f), fmaxf(y11, 0.f));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // attention (1x1 conv 256->1 + sigmoid), global average pool, classifier 256->256->128->64->1 (BN folded).
 // model.py:32-36,63-84,108-128.  One workgroup per patch.
 __global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, const float* __restrict__ att_w,
@@ -452,6 +698,17 @@ void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t
     const int grid = N * BANDS * (cfg.cout / (64 * CP));
     hipLaunchKernelGGL((lg_conv3x3_kernel<cfg.cin, cfg.cinp, cfg.cout, cfg.wi, cfg.pool, KC, PP, CP>), dim3(grid), dim3(256), 0,
                        s, in, c->wconv[L], c->bconv[L], out);
+}
+
+template <int L, int KC>
+void launch_wino_ws(const float* in, const LgCnn* c, float* out, int N, hipStream_t s, int num_cu) {
+    constexpr LayerCfg cfg = kLayers[L];
+    constexpr int TP = (cfg.wi / 2) * (cfg.wi / 2);
+    const int ntb = TP >= 32 ? N * (TP / 32) : (N + 32 / TP - 1) / (32 / TP);
+    const long long total = (long long)ntb * (cfg.cout / 64);
+    const int grid = (int)(total < num_cu ? total : num_cu);   // persistent: one workgroup per CU
+    hipLaunchKernelGGL((lg_wino_ws_kernel<cfg.cin, cfg.cout, cfg.wi, cfg.pool, KC>), dim3(grid), dim3(512), 0, s, in,
+                       c->uwino[L], c->bconv[L], out, N, ntb);
 }
 
 template <int L>
@@ -594,11 +851,25 @@ int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t
     // read per call.
     int wmask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
     if (const char* e = getenv("LG_CNN_WINO_MASK")) wmask = atoi(e) & 0x3e;
-    if (wmask & 2) launch_wino<1>(A, c, B, N, s); else launch_conv<1, 8, 4, 1>(A, c, B, N, s);   // 64 -> 64, pool -> 16x16
-    if (wmask & 4) launch_wino<2>(B, c, A, N, s); else launch_conv<2, 8, 4, 1>(B, c, A, N, s);   // 64 -> 128, 16x16
-    if (wmask & 8) launch_wino<3>(A, c, B, N, s); else launch_conv<3, 8, 4, 1>(A, c, B, N, s);   // 128 -> 128, pool -> 8x8
-    if (wmask & 16) launch_wino<4>(B, c, A, N, s); else launch_conv<4, 4, 1, 4>(B, c, A, N, s);  // 128 -> 256, 8x8
-    if (wmask & 32) launch_wino<5>(A, c, B, N, s); else launch_conv<5, 4, 1, 4>(A, c, B, N, s);  // 256 -> 256, pool -> 4x4
+    // default: the lock-step kernel (4.01 ms per 2560 patches); LG_CNN_WS_KC=8 selects the producer/consumer form (4.45 ms)
+    const int ws_kc = getenv("LG_CNN_WS_KC") ? atoi(getenv("LG_CNN_WS_KC")) : 0;  // read per call (tests)
+    static const int num_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (const char* e = getenv("LG_CNN_WS_GRID")) n = atoi(e);
+        return n > 0 ? n : 256;
+    }();
+#define LG_WINO(L, A_, B_)                                               \
+    do {                                                                 \
+        if (ws_kc == 8) launch_wino_ws<L, 8>(A_, c, B_, N, s, num_cu); \
+        else launch_wino<L>(A_, c, B_, N, s);                            \
+    } while (0)
+    if (wmask & 2) LG_WINO(1, A, B); else launch_conv<1, 8, 4, 1>(A, c, B, N, s);   // 64 -> 64, pool -> 16x16
+    if (wmask & 4) LG_WINO(2, B, A); else launch_conv<2, 8, 4, 1>(B, c, A, N, s);   // 64 -> 128, 16x16
+    if (wmask & 8) LG_WINO(3, A, B); else launch_conv<3, 8, 4, 1>(A, c, B, N, s);   // 128 -> 128, pool -> 8x8
+    if (wmask & 16) LG_WINO(4, B, A); else launch_conv<4, 4, 1, 4>(B, c, A, N, s);  // 128 -> 256, 8x8
+    if (wmask & 32) LG_WINO(5, A, B); else launch_conv<5, 4, 1, 4>(A, c, B, N, s);  // 256 -> 256, pool -> 4x4
+#undef LG_WINO
     hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_w, c->att_b, c->fcw[0], c->fcb[0], c->fcw[1],
                        c->fcb[1], c->fcw[2], c->fcb[2], c->fcw[3], c->fcb[3], logits);
     return LG_OK;

@@ -212,6 +212,12 @@ def test_cnn_winograd_matches_direct(sel, monkeypatch):
             np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), got[:n], err_msg=f"mask {mask} n {n}")
     monkeypatch.delenv("LG_CNN_WINO_MASK")
     np.testing.assert_allclose(sel.cnn_forward(x).cpu().numpy(), O.cnn_forward(params, x.cpu().numpy()), rtol=1e-4, atol=1e-5)
+    # the producer/consumer (persistent) form of the same layers: identical k order per accumulator -> identical bits
+    default = sel.cnn_forward(x).cpu().numpy()
+    monkeypatch.setenv("LG_CNN_WS_KC", "8")
+    for n in (41, 1, 2, 7):
+        np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"ws kernel n {n}")
+    monkeypatch.delenv("LG_CNN_WS_KC")
     sel.clear_cnn()
 
 
