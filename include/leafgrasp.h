@@ -178,6 +178,12 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
 int lg_profile_enable(lg_handle h, int on);
 int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_ms);
 
+/* Inspection of the last lg_score_maps / lg_select_grasp call on this handle (synchronises the device):
+   out[0], out[1] = max d_in, max d_out of frame `frame` in OpenCV's 16.16 fixed point (the normaliser
+   max|d_in - d_out| of calculate_sdf_score, grasp_point_selector.py:531-533, is their maximum / 65536);
+   win[0..3] (optional) = the distance-transform sweep window {x0, x1, y0, y1} (half open) used for that frame. */
+int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SYMBOLS = {
     "lg_leaf_orientation": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _FP, C.POINTER(C.c_int), _VP]),
     "lg_profile_enable": (C.c_int, [_VP, C.c_int]),
     "lg_profile_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "lg_debug_dt_max": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
 }
 
 

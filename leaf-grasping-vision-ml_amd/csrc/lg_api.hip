@@ -110,6 +110,7 @@ struct lg_ctx {
     uint32_t* tmp = nullptr;
     unsigned long long *bits = nullptr, *stem = nullptr, *tilekeys = nullptr;
     uint32_t* maxfix = nullptr;
+    LgWin* win = nullptr;           // [B] sweep windows (lg_bbox_kernel)
     LgFrameParams* fp_dev = nullptr;
     LgFrameParams* fp_host = nullptr;        // pinned
     unsigned long long* bits_host = nullptr;  // pinned
@@ -200,12 +201,12 @@ hipError_t dev_alloc(T** p, size_t n) {
 
 void free_ws(lg_ctx* h) {
     auto F = [](void* p) { if (p) hipFree(p); };
-    F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->fp_dev);
+    F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->win); F(h->fp_dev);
     for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps[i]); h->ws_maps[i] = nullptr; }
     F(h->ws_valid); F(h->cand_xy); F(h->cand_n); F(h->cand_info); F(h->patches); F(h->logits);
     auto HF = [](void* p) { if (p) hipHostFree(p); };
     HF(h->fp_host); HF(h->bits_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
-    h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->fp_dev = nullptr;
+    h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->win = nullptr; h->fp_dev = nullptr;
     h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
     h->fp_host = nullptr; h->bits_host = nullptr; h->bits_host_dev = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
     h->capB = h->capH = h->capW = h->capK = 0;
@@ -225,6 +226,7 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, dev_alloc(&h->stem, words));
     LG_HIP(h, dev_alloc(&h->tilekeys, (size_t)nB * tiles));
     LG_HIP(h, dev_alloc(&h->maxfix, (size_t)nB * 2));
+    LG_HIP(h, dev_alloc(&h->win, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->fp_dev, (size_t)nB));
     LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->bits_host, sizeof(unsigned long long) * words));
@@ -372,6 +374,22 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
     return LG_OK;
 }
 
+int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]) {
+    if (!h || !out || frame < 0 || frame >= h->capB || !h->maxfix) return LG_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (hipMemcpy(out, h->maxfix + 2 * (size_t)frame, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, LG_ERR_HIP, "lg_debug_dt_max: copy failed");
+    if (win) {
+        LgWin w;
+        if (hipMemcpy(&w, h->win + frame, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(h, LG_ERR_HIP, "lg_debug_dt_max: copy failed");
+        win[0] = w.wx0; win[1] = w.wx0 + w.nw * lg_dt_geometry(h->capW, nullptr); win[2] = w.wy0; win[3] = w.wy1;
+        if (win[1] > h->capW) win[1] = h->capW;
+    }
+    return LG_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -394,6 +412,10 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
         lg_launch_pack_bits(pl.mask + off * px, h->bits + off * words, n, pl.H, pl.W, pl.WW, s);
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
+    {
+        ProfScope ps(h, "bbox", s);
+        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, s);
+    }
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
     if (h->bits_host_dev && (((off * words) & 1) == 0))   // small-grid export kernel (see lg_export_kernel)
         lg_launch_export(h->bits + off * words, h->bits_host_dev + off * words, (long long)n * words, h->copy_stream);
@@ -416,13 +438,18 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     }
     {
         ProfScope ps(h, "dt_fwd", s);
-        if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, s))
+        if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, h->win + off, n,
+                         pl.H, pl.W, s))
             return fail(h, LG_ERR_UNSUPPORTED, "dt: width");
     }
     {
         ProfScope ps(h, "dt_bwd", s);
         lg_launch_dt(true, pl.mask + off * px, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
-                     h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, s);
+                     h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, s);
+    }
+    {
+        ProfScope ps(h, "dt_border", s);
+        lg_launch_dout_border(h->bits + off * words, h->win + off, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, pl.WW, s);
     }
     return LG_OK;
 }
@@ -455,6 +482,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     memset(&a, 0, sizeof(a));
     a.depth = pl.depth + off * px; a.bits = h->bits + off * words; a.stem_bits = h->stem + off * words;
     a.maxfix = h->maxfix + 2 * (size_t)off; a.fp = h->fp_dev + off;
+    a.win = h->win + off; a.win_wc = lg_dt_geometry(W, nullptr);
     for (int i = 0; i < LG_NUM_MAPS; i++) a.maps[i] = pl.maps[i] ? pl.maps[i] + off * px : nullptr;
     a.valid = pl.valid ? pl.valid + off * px : nullptr;
     a.tilekeys = h->tilekeys + (size_t)off * pl.tiles_x * pl.tiles_y;

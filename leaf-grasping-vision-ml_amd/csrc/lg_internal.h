@@ -21,6 +21,22 @@
 #define LG_TH 16   // measured at 1080p B=128: 16 -> 1.78 ms (0.69 of HBM peak), 32 -> 1.86 ms, 64 -> 2.11 ms
 #endif
 
+// Window of the distance-transform sweeps (per frame, written by lg_bbox_kernel).  The binary leaf mask covers a few
+// per cent of a frame, so the sweeps run on the tile-aligned window around its bounding box only:
+//   d_in  (distance to the nearest zero pixel): every pixel outside the window is itself a zero pixel -> exactly 0, and
+//         enters the window as a 0-valued halo: the windowed two-pass recurrence is the full-frame one, bit for bit.
+//   d_out (distance to the leaf; only max d_out is consumed): the two-pass 5x5 chamfer transform equals
+//         min over sources of the chamfer NORM (weights satisfy 2a <= c <= a+b, 3b <= 2c), shortest paths stay inside the
+//         bounding rectangle of their end points, so the window computed as a stand-alone image is exact inside; outside
+//         the window the distance grows monotonically towards the frame border, where lg_dout_border_kernel evaluates
+//         the norm in closed form against the leaf's row / column profiles.
+// Columns [wx0, wx0 + nw * 64 * E) (clipped to W), rows [wy0, wy1): wx0 % 64 == 0, wy0 % LG_TH == 0, so every tile of
+// the fused score-plane kernel is either inside (reads distance_map) or outside (writes zeros to it).
+struct LgWin {
+    int wx0, nw, wy0, wy1;   // window: first column, active waves (64*E columns each), row range
+    int bx0, bx1, by0, by1;  // bounding box of the mask (bx1 < bx0: empty mask -> window = whole frame)
+};
+
 struct LgFrameParams {  // per frame, written by the host after contour analysis
     float sin_t, cos_t;
     int has_angle;
@@ -39,6 +55,8 @@ struct LgFinalArgs {
     const unsigned long long* bits;
     const unsigned long long* stem_bits;
     const uint32_t* maxfix;       // [B][2] max fixed-point d_in / d_out
+    const LgWin* win;             // [B] sweep windows
+    int win_wc;                   // columns per sweep wave (64 * E)
     const LgFrameParams* fp;      // [B]
     float* maps[LG_NUM_MAPS];     // [B][H][W] each (may be null except DISTANCE/TRADITIONAL)
     uint8_t* valid;               // [B][H][W] or null
@@ -62,8 +80,14 @@ void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, i
 void lg_launch_export(const unsigned long long* src, unsigned long long* dst_host_devptr, long long nwords, hipStream_t s);
 void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,
                          int bottom_start, const LgSeSpans& se, hipStream_t s);
-int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
-                 hipStream_t s);
+// columns per sweep wave / waves per sweep workgroup for width W (0 if unsupported)
+int lg_dt_geometry(int W, int* waves);
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, hipStream_t s);
+int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,
+                 int H, int W, hipStream_t s);
+// max d_out outside the sweep windows (closed-form chamfer norm on the frame border) -> atomicMax into maxfix[b][1]
+void lg_launch_dout_border(const unsigned long long* bits, const LgWin* win, uint32_t* maxfix, int B, int H, int W, int WW,
+                           hipStream_t s);
 void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
                     bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,

@@ -234,6 +234,145 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
     hipLaunchKernelGGL(lg_stem_bits_kernel, grid, dim3(256), 0, s, bits, stem, H, W, WW, bottom_start, se);
 }
 
+// ============================================================================ sweep window (mask bounding box)
+// One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).
+__global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
+                                                      int H, int W, int WW, int wc, int nw_max) {
+    __shared__ int s_b[4];
+    const int frame = blockIdx.x, t = threadIdx.x;
+    if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; }
+    __syncthreads();
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    int x0 = INT_MAX, x1 = -1, y0 = INT_MAX, y1 = -1;
+    for (int y = t; y < H; y += 256) {
+        const unsigned long long* row = fb + (size_t)y * WW;
+        int first = -1, last = -1;
+        for (int w = 0; w < WW; w++) {
+            const unsigned long long v = row[w];
+            if (v) {
+                if (first < 0) first = 64 * w + __builtin_ctzll(v);
+                last = 64 * w + 63 - __builtin_clzll(v);
+            }
+        }
+        if (first >= 0) { x0 = min(x0, first); x1 = max(x1, last); y0 = min(y0, y); y1 = max(y1, y); }
+    }
+    if (x1 >= 0) {
+        atomicMin(&s_b[0], x0); atomicMax(&s_b[1], x1);
+        atomicMin(&s_b[2], y0); atomicMax(&s_b[3], y1);
+    }
+    __syncthreads();
+    if (t == 0) {
+        LgWin w;
+        w.bx0 = s_b[0]; w.bx1 = s_b[1]; w.by0 = s_b[2]; w.by1 = s_b[3];
+        if (w.bx1 < 0) {   // empty mask: no window (d_out has no source: the closed form of the whole frame applies)
+            w.bx0 = 0; w.bx1 = -1; w.by0 = 0; w.by1 = -1;
+            w.wx0 = 0; w.nw = nw_max; w.wy0 = 0; w.wy1 = H;
+        } else {
+            w.wx0 = (w.bx0 / LG_TW) * LG_TW;
+            w.nw = (w.bx1 + 1 - w.wx0 + wc - 1) / wc;
+            w.wy0 = (w.by0 / LG_TH) * LG_TH;
+            w.wy1 = min(H, ((w.by1 + 1 + LG_TH - 1) / LG_TH) * LG_TH);
+        }
+        wins[frame] = w;
+    }
+}
+
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
+    int nw = 0;
+    const int wc = lg_dt_geometry(W, &nw);
+    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(256), 0, s, bits, win, H, W, WW, wc, nw);
+}
+
+// ============================================================================ max d_out outside the sweep window
+// d_out(p) = min over leaf pixels q of the 5x5 chamfer norm N(p - q) (see LgWin).  Outside the window, moving p away
+// from the leaf's bounding box along x or y increases |dx| (|dy|) for EVERY leaf pixel, and N is monotone in |dx|, |dy|:
+// the maximum over the outside region sits on the frame border, and beyond the bounding box's span at a frame corner.
+// grid (4, B): side 0 = top row, 1 = bottom row, 2 = left column, 3 = right column.  For a candidate on the top row
+// only the topmost leaf pixel of each column can be the nearest one of that column (same dx, smallest dy), etc.
+__device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form norm of the (1, 1.4, 2.1969) chamfer mask
+    const uint32_t a = (uint32_t)max(dx, dy), b = (uint32_t)min(dx, dy);
+    return 2u * b <= a ? (a - 2u * b) * LG_A5 + b * LG_C5 : (a - b) * LG_C5 + (2u * b - a) * LG_B5;
+}
+__global__ __launch_bounds__(256) void lg_dout_border_kernel(const unsigned long long* __restrict__ bits,
+                                                             const LgWin* __restrict__ wins, uint32_t* __restrict__ maxfix,
+                                                             int H, int W, int WW, int wc) {
+    extern __shared__ int s_prof[];   // profile of the leaf seen from this side: distance from the border, -1 = no leaf pixel
+    const int side = blockIdx.x, frame = blockIdx.y, t = threadIdx.x;
+    const LgWin w = wins[frame];
+    if (w.bx1 < w.bx0) return;                       // empty mask: handled by the full-frame sweep
+    const int wxr = min(W, w.wx0 + w.nw * wc);
+    const bool need = side == 0 ? w.wy0 > 0 : side == 1 ? w.wy1 < H : side == 2 ? w.wx0 > 0 : wxr < W;
+    if (!need) return;                               // this border line lies inside the window: the sweep covers it
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    const bool horiz = side < 2;                     // candidates along x, profile indexed by column
+    const int lo = horiz ? w.bx0 : w.by0, hi = horiz ? w.bx1 : w.by1, n = hi - lo + 1;
+    if (horiz) {
+        // thread q owns one 64-column word of the bounding box and walks the rows from the border inwards, 8 rows per
+        // round trip; a column's profile entry is the row at which its bit is first seen
+        for (int i = t; i < n; i += 256) s_prof[i] = -1;
+        __syncthreads();
+        const int q = (w.bx0 >> 6) + t;
+        if (q <= (w.bx1 >> 6)) {
+            unsigned long long seen = 0;
+            const int rows = w.by1 - w.by0 + 1;
+            for (int r0 = 0; r0 < rows; r0 += 8) {
+                unsigned long long v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int r = min(r0 + j, rows - 1);
+                    const int y = side == 0 ? w.by0 + r : w.by1 - r;
+                    v[j] = fb[(size_t)y * WW + q];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    unsigned long long nb = v[j] & ~seen;
+                    seen |= v[j];
+                    const int r = min(r0 + j, rows - 1);
+                    const int dist = side == 0 ? w.by0 + r : H - 1 - (w.by1 - r);
+                    while (nb) {
+                        const int c = 64 * q + __builtin_ctzll(nb);
+                        nb &= nb - 1;
+                        s_prof[c - lo] = dist;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = t; i < n; i += 256) {
+            int d = -1;
+            const unsigned long long* row = fb + (size_t)(lo + i) * WW;
+            if (side == 2) {
+                for (int q = w.bx0 >> 6; q <= w.bx1 >> 6; q++) if (row[q]) { d = 64 * q + __builtin_ctzll(row[q]); break; }
+            } else {
+                for (int q = w.bx1 >> 6; q >= w.bx0 >> 6; q--) if (row[q]) { d = W - 1 - (64 * q + 63 - __builtin_clzll(row[q])); break; }
+            }
+            s_prof[i] = d;
+        }
+    }
+    __syncthreads();
+    // candidates: the span of the bounding box plus the two ends of the line
+    const int len = horiz ? W : H;
+    uint32_t best = 0;
+    for (int ci = t; ci < n + 2; ci += 256) {
+        const int p = ci < n ? lo + ci : (ci == n ? 0 : len - 1);
+        uint32_t dmin = 0xFFFFFFFFu;
+        for (int i = 0; i < n; i++) {
+            const int d = s_prof[i];
+            if (d >= 0) dmin = min(dmin, lg_norm5(abs(p - (lo + i)), d));
+        }
+        best = max(best, dmin);
+    }
+    best = lg_wave_max_u32(best);
+    if ((t & 63) == 0 && best) atomicMax(&maxfix[frame * 2 + 1], best);
+}
+
+void lg_launch_dout_border(const unsigned long long* bits, const LgWin* win, uint32_t* maxfix, int B, int H, int W, int WW,
+                           hipStream_t s) {
+    const int wc = lg_dt_geometry(W, nullptr);
+    const size_t shm = sizeof(int) * (size_t)max(H, W);
+    hipLaunchKernelGGL(lg_dout_border_kernel, dim3(4, B), dim3(256), shm, s, bits, win, maxfix, H, W, WW, wc);
+}
+
 // ============================================================================ chamfer 5x5 distance transform
 // cv2.distanceTransform(src, DIST_L2, 5)  (grasp_point_selector.py:266, :529-530).
 // Row-sequential emulation of the two raster sweeps; each image row is one segmented-free min-plus
@@ -243,10 +382,10 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
 // The backward sweep is the same code on the 180-degree-rotated image.
 template <int T, int E, bool BWD, bool VEC>
 __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ tmp,
-                                                   float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
-                                                   int W) {
+                                                   float* __restrict__ dist_out, uint32_t* __restrict__ maxfix,
+                                                   const LgWin* __restrict__ wins, int H, int W) {
     constexpr int NW = T / 64;
-    constexpr int WP = T * E;
+    constexpr int WC = 64 * E;                 // columns per wave
     constexpr int D = (BWD || E > 4) ? 4 : 8;  // rows per prefetch group (two groups are resident)
     // per row and wave: [0] inclusive wave total, [1..2] lane 0's first two pre-carry values,
     // [3..4] lane 63's last two pre-carry values, [5] lane 63's wave-local exclusive prefix
@@ -254,20 +393,36 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     const int which = blockIdx.x;
     const int frame = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // ---- sweep window (see LgWin): waves beyond it leave; s_barrier only counts the surviving waves
+    const LgWin win = wins[frame];
+    const int nwa = win.nw;
+    if (wave >= nwa) return;
+    const int wx0 = win.wx0, wxe = wx0 + nwa * WC;   // window columns [wx0, wxe); columns >= W are outside the image
+    const int wy0 = win.wy0, HW = win.wy1 - win.wy0; // window rows
     const size_t fo = (size_t)frame * H * W;
     const uint8_t* m = mask + fo;
     uint32_t* tp = tmp + ((size_t)frame * 2 + which) * H * W;
     float* dout = (dist_out && which == 0) ? dist_out + fo : nullptr;  // only d_in is a contract plane
-    const int pc0 = BWD ? WP - (t + 1) * E : t * E;  // first physical column of this thread (multiple of E)
+    const int pc0 = BWD ? wxe - (t + 1) * E : wx0 + t * E;  // first physical column of this thread (multiple of E)
     constexpr bool vec_ok = VEC;  // host guarantees W % E == 0 when VEC
     const bool full = vec_ok && (pc0 + E <= W);
-    const int c0 = t * E;  // first logical column
+    const int c0 = t * E;  // first logical column (0 = first window column in sweep order)
+    // value of a cell OUTSIDE the window: for d_in an in-image cell there is off the leaf, i.e. a source (0);
+    // for d_out, and outside the image, "no path".
+    auto outv = [&](int pc, int prow) -> uint32_t {
+        return (which == 0 && pc >= 0 && pc < W && prow >= 0 && prow < H) ? 0u : LG_INF;
+    };
+    auto phys_col = [&](int j) { return BWD ? wxe - 1 - j : wx0 + j; };          // logical -> physical column
+    auto phys_row = [&](int r) { return BWD ? win.wy1 - 1 - r : wy0 + r; };       // logical -> physical row
 
-    uint32_t p1[E + 4], p2[E + 2];
+    uint32_t p1[E + 4], p2[E + 2];   // previous row (columns c0-2 .. c0+E+1) and the one before (c0-1 .. c0+E)
 #pragma unroll
-    for (int i = 0; i < E + 4; i++) p1[i] = LG_INF;
+    for (int i = 0; i < E + 4; i++) p1[i] = outv(phys_col(c0 - 2 + i), phys_row(-1));
 #pragma unroll
-    for (int i = 0; i < E + 2; i++) p2[i] = LG_INF;
+    for (int i = 0; i < E + 2; i++) p2[i] = outv(phys_col(c0 - 1 + i), phys_row(-2));
+    // the cell left of the window in the current row (a source for d_in when it lies in the image)
+    const uint32_t edge_l1 = outv(phys_col(-1), wy0), edge_l2 = outv(phys_col(-2), wy0);
+    const uint32_t edge_r0 = outv(phys_col(nwa * WC), wy0), edge_r1 = outv(phys_col(nwa * WC + 1), wy0);
 
     // raw prefetch registers: forward = E mask bytes (packed in up to 2 dwords), backward = E dwords
     constexpr int RAWN = BWD ? E : (E + 3) / 4;
@@ -278,8 +433,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     // with vmcnt(0) at the join, which serialises every image row on HBM latency).
     const int pc0c = full ? pc0 : (vec_ok ? max(0, min(pc0, W - E)) : 0);
     auto load_row = [&](int r, uint32_t* dst) {  // r = logical row
-        const int rr = min(r, H - 1);
-        const int prow = BWD ? H - 1 - rr : rr;
+        const int prow = phys_row(min(r, HW - 1));
         if (vec_ok) {   // raw values only; out-of-image lanes are fixed up at the point of use
             if (BWD) {
                 const uint32_t* src = tp + (size_t)prow * W + pc0c;
@@ -323,7 +477,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 #pragma unroll
     for (int d = 0; d < D; d++) load_row(d, raw[d]);
 
-    for (int rb = 0; rb < H; rb += D) {
+    for (int rb = 0; rb < HW; rb += D) {
         // The whole next group is requested up front, so at the next iteration (where the compiler waits for
         // everything outstanding at the loop head) the youngest load is D rows old, not one.
 #pragma unroll
@@ -331,7 +485,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int r = rb + d;
-            if (r < H) {
+            if (r < HW) {
                 const int par = r & 1;
                 // ---- per-pixel upper bound ("init"): forward: source ? 0 : +inf ; backward: forward result
                 uint32_t init[E];
@@ -356,7 +510,9 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                     const uint32_t ma = p1[k + 2] + LG_A5;
                     v[k] = min(min(mc, mb), min(ma, init[k]));
                 }
-                // ---- same-row chain: thread-local, then across the workgroup
+                // ---- same-row chain: thread-local, then across the workgroup.  The cell left of the window enters through
+                //      thread 0's first pixel, so the prefix scan carries it along the whole row.
+                if (t == 0) v[0] = min(v[0], edge_l1 + LG_A5);
 #pragma unroll
                 for (int k = 1; k < E; k++) v[k] = min(v[k], v[k - 1] + LG_A5);
                 int mloc = (int)v[E - 1] - (int)((uint32_t)(c0 + E - 1) * LG_A5);
@@ -383,7 +539,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 #pragma unroll
                 for (int k = 0; k < E; k++) v[k] = min(v[k], cin + (uint32_t)(k + 1) * LG_A5);
                 // ---- write back
-                const int prow = BWD ? H - 1 - r : r;
+                const int prow = phys_row(r);
                 if (!BWD) {
                     uint32_t* dst = tp + (size_t)prow * W + pc0;
                     if (full) {
@@ -437,7 +593,9 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                     l0 = min((uint32_t)s_x[par][wave - 1][3], cprev + (uint32_t)(E - 1) * LG_A5);
                     l1 = min((uint32_t)s_x[par][wave - 1][4], cprev + (uint32_t)E * LG_A5);
                 }
-                if (lane == 63 && wave < NW - 1) {
+                if (t == 0) { l0 = edge_l2; l1 = edge_l1; }
+                if (lane == 63 && wave == nwa - 1) { r0 = edge_r0; r1 = edge_r1; }
+                if (lane == 63 && wave < nwa - 1) {
                     // final values of thread t+1 (lane 0 of the next wave): its carry is the prefix over all threads <= t
                     const int inc = min(s_x[par][wave][0], wpre);
                     const uint32_t cnext = (uint32_t)(inc + (int)((uint32_t)(c0 + E - 1) * LG_A5));
@@ -462,40 +620,58 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 }
 
 template <int T, int E>
-static void lg_dt_launch_t(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B,
-                           int H, int W, hipStream_t s) {
+static void lg_dt_launch_t(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
+                           const LgWin* win, int B, int H, int W, hipStream_t s) {
     dim3 grid(2, B), block(T);
     const bool vec = (W % E) == 0 && W >= E;
     if (bwd) {
-        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
-        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
     } else {
-        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
-        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, H, W);
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
     }
 }
 
-int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, int B, int H, int W,
-                 hipStream_t s) {
+// threads x columns-per-thread of the sweep workgroup for width W: returns 64 * E, *waves = T / 64 (0: unsupported)
+int lg_dt_geometry(int W, int* waves) {
+    static const int force_e = getenv("LG_DT_E") ? atoi(getenv("LG_DT_E")) : 0;
+    int T, E;
+    if (force_e == 8) {
+        E = 8;
+        T = W <= 512 ? 64 : W <= 1024 ? 128 : W <= 2048 ? 256 : W <= 4096 ? 512 : W <= 8192 ? 1024 : 0;
+    } else if (W <= 2048) {
+        E = 4;
+        T = W <= 256 ? 64 : W <= 512 ? 128 : W <= 1024 ? 256 : 512;
+    } else {
+        E = 8;
+        T = W <= 4096 ? 512 : W <= 8192 ? 1024 : 0;
+    }
+    if (waves) *waves = T / 64;
+    return T ? 64 * E : 0;
+}
+
+int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,
+                 int H, int W, hipStream_t s) {
     // threads * E columns must cover the row.  E = 4 keeps the per-row dependency chain short (best up to
     // 2048 columns: 0.70/0.82 ms vs 0.82/0.91 ms at 1080p); at 4K 512x8 beats 1024x4 (2.04/2.54 vs 2.65/3.12 ms).
     // LG_DT_E=8 forces 8 columns per thread (experiments).
     static const int force_e = getenv("LG_DT_E") ? atoi(getenv("LG_DT_E")) : 0;
     if (force_e == 8) {
-        if (W <= 512) lg_dt_launch_t<64, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-        else if (W <= 1024) lg_dt_launch_t<128, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-        else if (W <= 2048) lg_dt_launch_t<256, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-        else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-        else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+        if (W <= 512) lg_dt_launch_t<64, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+        else if (W <= 1024) lg_dt_launch_t<128, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+        else if (W <= 2048) lg_dt_launch_t<256, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+        else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+        else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
         else return -1;
         return 0;
     }
-    if (W <= 256) lg_dt_launch_t<64, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-    else if (W <= 512) lg_dt_launch_t<128, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-    else if (W <= 1024) lg_dt_launch_t<256, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-    else if (W <= 2048) lg_dt_launch_t<512, 4>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
-    else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);   // 4K: 8 waves beat 16 (measured)
-    else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, B, H, W, s);
+    if (W <= 256) lg_dt_launch_t<64, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+    else if (W <= 512) lg_dt_launch_t<128, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+    else if (W <= 1024) lg_dt_launch_t<256, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+    else if (W <= 2048) lg_dt_launch_t<512, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+    else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);   // 4K: 8 waves beat 16 (measured)
+    else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
     else return -1;
     return 0;
 }
@@ -540,6 +716,10 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
     constexpr int RPT = LG_TH / 16;   // rows per thread (16 thread rows per tile)
     static_assert(LG_TH % 16 == 0 && RPT >= 1, "tile height must be a multiple of 16");
+    // distance_map is only computed inside the frame's sweep window (LgWin, tile aligned); outside it is exactly 0 and
+    // this kernel writes the plane instead of reading it
+    const LgWin win = a.win[frame];
+    const bool in_win = tx0 >= win.wx0 && tx0 < min(W, win.wx0 + win.nw * a.win_wc) && ty0 >= win.wy0 && ty0 < win.wy1;
     float din_pre[RPT][4];
     unsigned mnib_pre[RPT], snib_pre[RPT];
 #pragma unroll
@@ -553,7 +733,8 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
             mnib_pre[rr] = (unsigned)(bits[(size_t)y * WW + bx] >> sh) & 0xfu;
             snib_pre[rr] = (unsigned)(stemb[(size_t)y * WW + bx] >> sh) & 0xfu;
             const float* dsrc = a.maps[LG_MAP_DISTANCE] + fo + (size_t)y * W + x0;
-            if (vec) {
+            if (!in_win) {
+            } else if (vec) {
                 float4 v = *reinterpret_cast<const float4*>(dsrc);
                 din_pre[rr][0] = v.x; din_pre[rr][1] = v.y; din_pre[rr][2] = v.z; din_pre[rr][3] = v.w;
             } else {
@@ -747,6 +928,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
             st4(LG_MAP_ACCESS, o_acc);
             st4(LG_MAP_STEM, o_stem);
             st4(LG_MAP_TRADITIONAL, o_trad);
+            if (!in_win) { const float z4[4] = {0.f, 0.f, 0.f, 0.f}; st4(LG_MAP_DISTANCE, z4); }
             if (a.valid) {
                 if (vec) {
                     __builtin_nontemporal_store(vbytes, reinterpret_cast<uint32_t*>(a.valid + off));

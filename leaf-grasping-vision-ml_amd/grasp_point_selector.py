@@ -154,6 +154,17 @@ class GraspPointSelector:
         th = [None if math.isnan(t) else float(t) for t in theta]
         return out, (valid[0] if squeeze else valid), (th[0] if squeeze else th)
 
+    def dt_maxima(self, frame=0):
+        """Inspection: (max d_in, max d_out) of `frame` in the last call, as float32 like cv2's planes
+        (grasp_point_selector.py:529-533), and the sweep window (x0, x1, y0, y1) the distance transforms ran on."""
+        import ctypes as C
+        out, win = (C.c_uint32 * 2)(), (C.c_int32 * 4)()
+        rc = lib.lg_debug_dt_max(self._h, int(frame), out, win)
+        if rc != 0:
+            raise RuntimeError(lib.lg_last_error(self._h).decode())
+        scale = np.float32(1.0 / 65536.0)
+        return np.float32(out[0]) * scale, np.float32(out[1]) * scale, tuple(win)
+
     def _calculate_all_scores(self, leaf_mask_np, depth_tensor, image_processor=None):
         """Reference signature (:256): numpy uint8 mask in, dict of numpy planes out."""
         out, _, _ = self.score_maps(leaf_mask_np, depth_tensor)

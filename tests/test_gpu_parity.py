@@ -89,6 +89,70 @@ def test_score_maps_edge_cases(sel):
         _compare_maps(sel, m, depth, P)
 
 
+def _window_case(rng, H, W, kind):
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = np.zeros((H, W), np.uint8)
+
+    def blob(cx, cy, a, b, ang):
+        t = np.deg2rad(ang)
+        u = (xx - cx) * np.cos(t) + (yy - cy) * np.sin(t)
+        v = -(xx - cx) * np.sin(t) + (yy - cy) * np.cos(t)
+        return (u / a) ** 2 + (v / b) ** 2 <= 1.0
+
+    if kind == 0:      # one small leaf anywhere (also hanging over the frame border)
+        m |= blob(rng.uniform(-10, W + 10), rng.uniform(-10, H + 10), rng.uniform(5, W / 4), rng.uniform(4, H / 4), rng.uniform(0, 180))
+    elif kind == 1:    # two far components: the window spans both, the gap rows / columns have no leaf pixel
+        m |= blob(rng.uniform(0, W / 3), rng.uniform(0, H / 3), rng.uniform(3, 20), rng.uniform(3, 20), rng.uniform(0, 180))
+        m |= blob(rng.uniform(2 * W / 3, W), rng.uniform(2 * H / 3, H), rng.uniform(3, 20), rng.uniform(3, 20), rng.uniform(0, 180))
+    elif kind == 2:    # ring: d_out has an interior maximum (the hole), d_in a thin band
+        r = np.hypot(yy - rng.uniform(H / 3, 2 * H / 3), xx - rng.uniform(W / 3, 2 * W / 3))
+        r0 = rng.uniform(6, min(H, W) / 3)
+        m |= (r < r0) & (r > r0 * rng.uniform(0.3, 0.8))
+    elif kind == 3:    # single pixels / thin lines (corners included)
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(H)), int(rng.integers(W))] = 1
+        if rng.random() < 0.5:
+            m[int(rng.integers(H)), :] = 1
+        if rng.random() < 0.3:
+            m[0, 0] = 1
+        if rng.random() < 0.3:
+            m[H - 1, W - 1] = 1
+    elif kind == 4:    # concave "C": the far point of d_out is not a frame corner of the window
+        m[H // 4:3 * H // 4, W // 4:3 * W // 4] = 1
+        m[H // 3:2 * H // 3, W // 3:3 * W // 4] = 0
+    else:              # leaf touching one frame border
+        side = int(rng.integers(4))
+        cx = (0, W - 1, rng.uniform(0, W), rng.uniform(0, W))[side]
+        cy = (rng.uniform(0, H), rng.uniform(0, H), 0, H - 1)[side]
+        m |= blob(cx, cy, rng.uniform(5, W / 5), rng.uniform(5, H / 5), rng.uniform(0, 180))
+    return m.astype(np.uint8)
+
+
+def test_windowed_sweeps_are_exact(sel):
+    """The distance transforms run on the tile-aligned window around the leaf's bounding box; max d_out outside it comes
+    from the closed-form chamfer norm on the frame border.  Both must reproduce the full-frame two-pass transform of the
+    oracle bit for bit: distance_map, max d_in and max d_out (the sdf normaliser, grasp_point_selector.py:531-533)."""
+    rng = np.random.default_rng(77)
+    shapes = [(96, 128), (150, 333), (210, 520), (300, 1030), (64, 64), (131, 258)]
+    n_windowed = 0
+    for case in range(60):
+        H, W = shapes[case % len(shapes)]
+        mask = _window_case(rng, H, W, case % 6)
+        if mask.sum() == 0:
+            mask[H // 2, W // 2] = 1
+        depth = np.full((H, W), 0.5, np.float32)
+        maps, _, _ = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda())
+        d_in = O.distance_transform(mask, 5)
+        d_out = O.distance_transform(1 - mask, 5)
+        msg = f"case {case} kind {case % 6} {H}x{W}"
+        np.testing.assert_array_equal(maps["distance_map"].cpu().numpy(), d_in, err_msg=msg)
+        mi, mo, win = sel.dt_maxima(0)
+        assert mi == d_in.max(), msg
+        assert mo == d_out.max(), f"{msg}: max d_out {mo} vs {d_out.max()} (window {win})"
+        n_windowed += (win[1] - win[0]) * (win[3] - win[2]) < H * W
+    assert n_windowed >= 20   # the windowed path was actually exercised
+
+
 def test_batch_equals_single(sel):
     H, W = 135, 180
     frames = [O.synthetic_scene(H, W, s) for s in range(5)]
