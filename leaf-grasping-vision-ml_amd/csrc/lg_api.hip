@@ -115,7 +115,9 @@ struct lg_ctx {
     LgFrameParams* fp_host = nullptr;        // pinned
     unsigned long long* bits_host = nullptr;  // pinned
     unsigned long long* bits_host_dev = nullptr;  // device-side alias of bits_host (zero-copy export)
+    LgWin* win_host = nullptr;                 // pinned copy of the sweep windows / bounding boxes
     float* ws_maps[LG_NUM_MAPS] = {nullptr};
+    float* ws_maps_base[LG_NUM_MAPS] = {nullptr};  // allocation bases (ws_maps[i] = base + i * skew)
     uint8_t* ws_valid = nullptr;
     int32_t *cand_xy = nullptr, *cand_n = nullptr;
     float *cand_info = nullptr, *patches = nullptr, *logits = nullptr;
@@ -202,13 +204,13 @@ hipError_t dev_alloc(T** p, size_t n) {
 void free_ws(lg_ctx* h) {
     auto F = [](void* p) { if (p) hipFree(p); };
     F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->win); F(h->fp_dev);
-    for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps[i]); h->ws_maps[i] = nullptr; }
+    for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps_base[i]); h->ws_maps_base[i] = h->ws_maps[i] = nullptr; }
     F(h->ws_valid); F(h->cand_xy); F(h->cand_n); F(h->cand_info); F(h->patches); F(h->logits);
     auto HF = [](void* p) { if (p) hipHostFree(p); };
-    HF(h->fp_host); HF(h->bits_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
+    HF(h->fp_host); HF(h->bits_host); HF(h->win_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
     h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->win = nullptr; h->fp_dev = nullptr;
     h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
-    h->fp_host = nullptr; h->bits_host = nullptr; h->bits_host_dev = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
+    h->fp_host = nullptr; h->bits_host = nullptr; h->win_host = nullptr; h->bits_host_dev = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
     h->capB = h->capH = h->capW = h->capK = 0;
 }
 
@@ -229,11 +231,12 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, dev_alloc(&h->win, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->fp_dev, (size_t)nB));
     LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
+    LG_HIP(h, hipHostMalloc((void**)&h->win_host, sizeof(LgWin) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->bits_host, sizeof(unsigned long long) * words));
     // LG_EXPORT_KERNEL=1 replaces the D2H memcpy by a 32-workgroup zero-copy kernel (measured slower: the sweeps
     // finish at 2.23 ms vs 1.73 ms with the memcpy on the priority stream); kept for experiments only.
-    if (!getenv("LG_EXPORT_KERNEL") || hipHostGetDevicePointer((void**)&h->bits_host_dev, h->bits_host, 0) != hipSuccess)
-        h->bits_host_dev = nullptr;
+    if (getenv("LG_EXPORT_MEMCPY") || hipHostGetDevicePointer((void**)&h->bits_host_dev, h->bits_host, 0) != hipSuccess)
+        h->bits_host_dev = nullptr;   // fall back to a full-batch hipMemcpyAsync
     LG_HIP(h, dev_alloc(&h->cand_xy, (size_t)nB * nK * 2));
     LG_HIP(h, dev_alloc(&h->cand_n, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->cand_info, (size_t)nB * nK * 2));
@@ -249,7 +252,11 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
 
 int ensure_ws_map(lg_ctx* h, int i) {  // internal plane when the caller does not want map i
     if (h->ws_maps[i]) return LG_OK;
-    LG_HIP(h, dev_alloc(&h->ws_maps[i], (size_t)h->capB * h->capH * h->capW));
+    // LG_PLANE_SKEW=<floats>: plane i starts i * skew floats into its allocation, so that the eight planes' equal pixel
+    // offsets do not land on the same HBM channel (experiment; 0 = off)
+    static const size_t skew = getenv("LG_PLANE_SKEW") ? (size_t)atoi(getenv("LG_PLANE_SKEW")) / 4 * 4 : 0;
+    LG_HIP(h, dev_alloc(&h->ws_maps_base[i], (size_t)h->capB * h->capH * h->capW + LG_NUM_MAPS * skew));
+    h->ws_maps[i] = h->ws_maps_base[i] + (size_t)i * skew;
     return LG_OK;
 }
 
@@ -411,17 +418,18 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
         ProfScope ps(h, "prep", s);
         lg_launch_pack_bits(pl.mask + off * px, h->bits + off * words, n, pl.H, pl.W, pl.WW, s);
     }
-    LG_HIP(h, hipEventRecord(ev_prep, s));
     {
         ProfScope ps(h, "bbox", s);
         lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, s);
     }
+    LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
-    if (h->bits_host_dev && (((off * words) & 1) == 0))   // small-grid export kernel (see lg_export_kernel)
-        lg_launch_export(h->bits + off * words, h->bits_host_dev + off * words, (long long)n * words, h->copy_stream);
+    if (h->bits_host_dev)   // rows of the bounding boxes only, posted writes by a small grid on the priority stream
+        lg_launch_export_rows(h->bits + off * words, h->win + off, h->bits_host_dev + off * words, n, pl.H, pl.WW, h->copy_stream);
     else
         LG_HIP(h, hipMemcpyAsync(h->bits_host + off * words, h->bits + off * words, sizeof(unsigned long long) * n * words,
                                  hipMemcpyDeviceToHost, h->copy_stream));
+    LG_HIP(h, hipMemcpyAsync(h->win_host + off, h->win + off, sizeof(LgWin) * n, hipMemcpyDeviceToHost, h->copy_stream));
     LG_HIP(h, hipEventRecord(ev_copy, h->copy_stream));
     return LG_OK;
 }
@@ -458,11 +466,15 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
 void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
     const unsigned long long* hb = h->bits_host;
     LgFrameParams* fph = h->fp_host;
+    const LgWin* wh = h->win_host;
     const int H = pl.H, W = pl.W, WW = pl.WW;
     parallel_for(h, n, [=](int i) {
         const int b = off + i;
         double o[5];
-        int ok = lg_host_orientation(hb + (size_t)b * H * WW, H, W, WW, o);
+        // only the rows of the bounding box are on the host: analyse them as a sub-image (the rest is all zero)
+        const LgWin& w = wh[b];
+        const int hy = w.by1 - w.by0 + 1;
+        int ok = hy > 0 ? lg_host_orientation(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, o) : 0;
         LgFrameParams f;
         f.has_angle = ok;
         f.theta = ok ? (float)o[0] : NAN;
@@ -804,6 +816,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     const float* all_info = h->h_info;
     const float* all_logits = h->h_logits;
     const unsigned long long* all_bits = h->bits_host;
+    const LgWin* all_win = h->win_host;
     const float* thp = theta.data();
     parallel_for(h, B, [=, &P, &pre_se](int b) {
         lg_grasp_result& R = results[b];
@@ -841,7 +854,9 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         const double nrm = sqrt(X * X + Y * Y + Z * Z);
         if (!(nrm > 0.0) || !std::isfinite(nrm)) { R.has_pre = 0; return; }  // reference: exception -> None
         const double dxn = X / nrm, dyn = Y / nrm;
-        const unsigned long long* hb = all_bits + (size_t)b * H * WW;
+        const LgWin& bw = all_win[b];          // host bit rows exist for the bounding-box rows only
+        const int hy = bw.by1 - bw.by0 + 1;
+        const unsigned long long* hb = all_bits + ((size_t)b * H + (hy > 0 ? bw.by0 : 0)) * WW;
         bool done = false;
         for (int step = 0; step < 5 && !done; step++) {
             // np.arange(0.05, 0.10, 0.01)[step] = start + step * ((start + delta) - start)
@@ -850,7 +865,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
             const int u = (int)((tx * (double)P.f / tz) + (double)P.cx);
             const int v = (int)((ty * (double)P.f / tz) + (double)P.cy);
             if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
-            if (!lg_host_ellipse_hit_se(hb, H, W, WW, u, v, pre_se)) {
+            if (!(hy > 0 && lg_host_ellipse_hit_se(hb, hy, W, WW, u, v - bw.by0, pre_se))) {
                 const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
                 if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
             }

@@ -167,6 +167,26 @@ void lg_launch_export(const unsigned long long* src, unsigned long long* dst_hos
         hipMemcpyAsync(dst_host_devptr + nwords - 1, src + nwords - 1, 8, hipMemcpyDeviceToDevice, s);
 }
 
+// Export of the bit rows the host needs -- the rows of each frame's bounding box only (a leaf covers a third of the
+// frame height: 3-4x less PCIe traffic than the whole batch) -- by posted 8-byte writes into the pinned host image,
+// which keeps its [B][H][WW] layout; rows outside the bounding box are all zero and never read by the host.
+__global__ __launch_bounds__(256) void lg_export_rows_kernel(const unsigned long long* __restrict__ bits,
+                                                             const LgWin* __restrict__ wins,
+                                                             unsigned long long* __restrict__ dst_host, int H, int WW) {
+    const int frame = blockIdx.y;
+    const LgWin w = wins[frame];
+    if (w.bx1 < w.bx0) return;
+    const size_t base = ((size_t)frame * H + w.by0) * WW;
+    const long long n = (long long)(w.by1 - w.by0 + 1) * WW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst_host[base + i] = bits[base + i];
+}
+
+void lg_launch_export_rows(const unsigned long long* bits, const LgWin* wins, unsigned long long* dst_host_devptr, int B,
+                           int H, int WW, hipStream_t s) {
+    hipLaunchKernelGGL(lg_export_rows_kernel, dim3(2, B), dim3(256), 0, s, bits, wins, dst_host_devptr, H, WW);
+}
+
 // ============================================================================ stem penalty (binary dilation on bit rows)
 // stem = dilate(mask & bottom_region, ellipse k) & mask     (grasp_point_selector.py:688-701)
 // dilate(x,y) = OR over SE rows i, dx in [lo_i, hi_i] of src(x+dx, y+i-anchor)  (cv2.dilate, anchor k/2)
