@@ -26,6 +26,8 @@ __device__ float lg_zero_pad[4];  // zero-initialised source for padded / out-of
 namespace {
 
 struct LayerCfg { int cin, cinp, cout, wi; bool pool; };
+constexpr size_t kActPerPatch = 64 * 32 * 32;   // largest activation plane set per patch (conv1 output), floats
+constexpr size_t kZeroTail = 64 * 32 * 32 + 1024;  // zeroed floats behind each activation buffer (>= CIN*WI*WI of any layer)
 constexpr LayerCfg kLayers[6] = {
     {9, 10, 64, 32, false}, {64, 64, 64, 32, true},   {64, 64, 128, 16, false},
     {128, 128, 128, 16, true}, {128, 128, 256, 8, false}, {256, 256, 256, 8, true}};
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 template <int CIN, int COUT, int WI, bool POOL>
 __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       int N, int ntb) {
+                                                       const float* __restrict__ zero_tail, int N, int ntb) {
     constexpr int KC = 8;                                  // input channels per chunk (2 MFMA k-steps)
     constexpr int TC = WI / 2, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup (8x8 images: 2)
@@ -228,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float s_mem[2 * NIN * 256 + KC * 32 * VS];
     float* const s_v = s_mem + 2 * NIN * 256;
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) stay on the SALU
     // XCD-aware order: an XCD walks consecutive (tile block, channel block) pairs, so the NCB workgroups that
     // share an input band run back to back on one L2.
     long long id = blockIdx.x;
@@ -243,8 +246,13 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     const int y0 = band * 2 * TROWS;                       // first output row of the band
     const int co0 = cb * 64;
 
-    // ---- input staging offsets (chunk invariant)
-    int off_in[NIN];
+    // ---- input staging: chunk-invariant 32-bit byte offsets from a wave-uniform base that advances per chunk
+    //      (global_load_lds saddr + voffset form: issuing a chunk costs ~3 instructions per load).  Conv padding and
+    //      unused slots read zeros from `zero_tail`, a zeroed region >= CIN*WI*WI floats behind the activation buffer:
+    //      their offsets advance with the base like everybody else's and stay inside it.
+    const float* in_n = in + (size_t)n0 * CIN * WI * WI;
+    const unsigned tail_rel = (unsigned)((const char*)zero_tail - (const char*)in_n);
+    unsigned voff[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
         const int e = t + 256 * j;
@@ -253,18 +261,15 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
         const int ry = r2 / RW, rx = r2 % RW;
         const int gy = y0 - 1 + ry, gx = rx - 1;
         const bool ok = e < KC * S && gy >= 0 && gy < WI && gx >= 0 && gx < WI && n0 + pb < N;
-        off_in[j] = ok ? ((pb * CIN + ci) * WI + gy) * WI + gx : -1;
+        voff[j] = ok ? 4u * (unsigned)(((pb * CIN + ci) * WI + gy) * WI + gx) : tail_rel;
     }
-    const float* in_n = in + (size_t)n0 * CIN * WI * WI;
     auto issue_input = [&](int c, int stage) {
-        const float* in_c = in_n + (size_t)c * KC * WI * WI;
+        const char* in_c = (const char*)(in_n + (size_t)c * KC * WI * WI);
         float* sb = s_mem + stage * (NIN * 256);
 #pragma unroll
-        for (int j = 0; j < NIN; j++) {
-            const float* src = off_in[j] >= 0 ? in_c + off_in[j] : lg_zero_pad;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        for (int j = 0; j < NIN; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in_c + voff[j]),
                                              (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
-        }
     };
     // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co]
     const float* u_lane = U + ((size_t)(lane >> 4) * COUT + co0 + 16 * wave + (lane & 15)) * 16;
@@ -717,8 +722,10 @@ void launch_wino(const float* in, const LgCnn* c, float* out, int N, hipStream_t
     constexpr int TP = (cfg.wi / 2) * (cfg.wi / 2);
     const int ntb = TP >= 32 ? N * (TP / 32) : (N + 32 / TP - 1) / (32 / TP);
     const int grid = ntb * (cfg.cout / 64);
+    // the zeroed tail sits behind BOTH ping-pong buffers at the same element offset; `in` is one of them
+    const float* zero_tail = in + (size_t)c->capN * kActPerPatch;
     hipLaunchKernelGGL((lg_wino_kernel<cfg.cin, cfg.cout, cfg.wi, cfg.pool>), dim3(grid), dim3(256), 0, s, in, c->uwino[L],
-                       c->bconv[L], out, N, ntb);
+                       c->bconv[L], out, zero_tail, N, ntb);
 }
 
 }  // namespace
@@ -827,20 +834,36 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
     return LG_OK;
 }
 
+static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err);
+
+// Slices of at most kMaxSlice patches share the activation workspace (the 32-bit staging offsets of lg_wino_kernel
+// reach 4 GiB; 8192 patches = 2 GiB of activations per buffer).
 int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
     if (!c->loaded) { *err = "no model"; return LG_ERR_NO_MODEL; }
+    constexpr int kMaxSlice = 8192;
+    for (int off = 0; off < N; off += kMaxSlice) {
+        const int n = N - off < kMaxSlice ? N - off : kMaxSlice;
+        int rc = lg_cnn_run_slice(c, patches + (size_t)off * 9 * 1024, n, logits + off, s, err);
+        if (rc) return rc;
+    }
+    return LG_OK;
+}
+
+static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
     if (N > c->capN) {
         hipStreamSynchronize(s);
         if (c->act[0]) hipFree(c->act[0]);
         if (c->act[1]) hipFree(c->act[1]);
         c->act[0] = c->act[1] = nullptr;
-        const size_t per = 64 * 32 * 32;  // largest activation plane set per patch (conv1 output)
-        if (hipMalloc((void**)&c->act[0], (size_t)N * per * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&c->act[1], (size_t)N * per * sizeof(float)) != hipSuccess) {
+        const size_t per = kActPerPatch;
+        if (hipMalloc((void**)&c->act[0], ((size_t)N * per + kZeroTail) * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&c->act[1], ((size_t)N * per + kZeroTail) * sizeof(float)) != hipSuccess) {
             *err = "lg_cnn_forward: activation workspace allocation failed";
             c->capN = 0;
             return LG_ERR_NOMEM;
         }
+        hipMemsetAsync(c->act[0] + (size_t)N * per, 0, kZeroTail * sizeof(float), s);
+        hipMemsetAsync(c->act[1] + (size_t)N * per, 0, kZeroTail * sizeof(float), s);
         c->capN = N;
     }
     float *A = c->act[0], *B = c->act[1];
