@@ -474,7 +474,7 @@ void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
         // only the rows of the bounding box are on the host: analyse them as a sub-image (the rest is all zero)
         const LgWin& w = wh[b];
         const int hy = w.by1 - w.by0 + 1;
-        int ok = hy > 0 ? lg_host_orientation(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, o) : 0;
+        int ok = hy > 0 ? lg_host_orientation_rows(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, w.by0, o) : 0;
         LgFrameParams f;
         f.has_angle = ok;
         f.theta = ok ? (float)o[0] : NAN;

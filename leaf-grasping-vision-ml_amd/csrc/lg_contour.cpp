@@ -139,6 +139,13 @@ int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, in
 }
 
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out) {
+    return lg_host_orientation_rows(bits, H, W, WW, 0, out);
+}
+
+// Same analysis on a band of rows: `bits` points at image row y_off and H is the band height (every other row of the
+// image is empty).  Hull and rectangle are computed in ABSOLUTE image coordinates, so ties between candidate rectangles
+// (decided by the last bits of double arithmetic) fall exactly as they do for the whole image.
+int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out) {
     std::vector<Run> runs;
     std::vector<int> row_start(H + 1, 0);
     // ---- runs per row
@@ -192,8 +199,8 @@ int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, do
     std::vector<P2> pts;
     for (int i = 0; i < (int)runs.size(); i++)
         if (find_root(runs, i) == best_root) {
-            pts.push_back({runs[i].x0, runs[i].y});
-            if (runs[i].x1 != runs[i].x0) pts.push_back({runs[i].x1, runs[i].y});
+            pts.push_back({runs[i].x0, runs[i].y + y_off});
+            if (runs[i].x1 != runs[i].x0) pts.push_back({runs[i].x1, runs[i].y + y_off});
         }
     std::sort(pts.begin(), pts.end(), [](const P2& a, const P2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
     std::vector<P2> hull(2 * pts.size() + 2);

@@ -100,6 +100,8 @@ void lg_launch_gather(const float* depth, const uint8_t* mask, const float* cons
 // host-side contour analysis on the bit-packed mask (lg_contour.cpp)
 // returns 1 and fills out[0..4] = angle(rad,(0,pi]), major, minor, cx, cy ; 0 if the mask is empty
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out);
+// the same on the band of rows [y_off, y_off + H) (bits -> row y_off); results in absolute image coordinates
+int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out);
 // 1 if any set bit of `bits` lies under the (2c+1)^2 ellipse centred at (u,v)  (pre-grasp clearance probe)
 int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance);
 int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW, int u, int v, const LgSeSpans& se);

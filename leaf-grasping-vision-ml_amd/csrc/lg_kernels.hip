@@ -730,7 +730,6 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     const float* depth = a.depth + fo;
     const unsigned long long* bits = a.bits + (size_t)frame * H * WW;
 
-    // ---- issue the per-pixel operands first so their HBM latency overlaps the stencil phases
     const int txi = t & 15, tyi = t >> 4;
     const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
     const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
@@ -740,6 +739,70 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
     // this kernel writes the plane instead of reading it
     const LgWin win = a.win[frame];
     const bool in_win = tx0 >= win.wx0 && tx0 < min(W, win.wx0 + win.nw * a.win_wc) && ty0 >= win.wy0 && ty0 < win.wy1;
+    // ---- tile-level fast path.  A leaf covers a few per cent of the frame: when no mask bit lies in this tile's extended
+    //      region (tile + the 3-pixel reach of the 5x5 Gaussian and 3x3 Sobel), depth * mask is 0 all over it, the smoothed
+    //      plane and both gradients are 0 and flatness = exp(-5 * 0) = 1 exactly; every other plane is "* mask" = 0,
+    //      traditional = w_flat * 1, nothing is valid.  Such tiles never read depth and skip the stencil phases.
+    {
+        unsigned long long nz = 0;
+        if (t < DH * 3 && !a.no_skip) {
+            const int er = t / 3, wq = t % 3;                 // extended row, word (left neighbour, own, right neighbour)
+            const int y = lg_reflect(ty0 - 3 + er, H), wi = bx - 1 + wq;
+            if (wi >= 0 && wi < WW) {
+                nz = bits[(size_t)y * WW + wi];
+                if (wq == 0) nz >>= 56;                       // columns tx0-8 .. tx0-1 (halo 4 + reflection slack)
+                if (wq == 2) nz &= 0xffull;                   // columns tx0+64 .. tx0+71
+            }
+        }
+        if (!a.no_skip && !__syncthreads_or(nz != 0)) {
+            const float flat1 = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(0.0f));
+            const float c_flat[4] = {flat1, flat1, flat1, flat1};
+            const float tr = a.w_flat * flat1;
+            const float c_trad[4] = {tr, tr, tr, tr};
+            const float c_zero[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) {
+                const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
+                if (y < H && x0 < W) {
+                    const size_t off = fo + (size_t)y * W + x0;
+                    auto st4c = [&](int mi, const float* v) {
+                        float* dst = a.maps[mi];
+                        if (!dst) return;
+                        if (vec) {
+                            typedef float lg_f4 __attribute__((ext_vector_type(4)));
+                            lg_f4 pk = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<lg_f4*>(dst + off) = pk;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (x0 + j < W) dst[off + j] = v[j];
+                        }
+                    };
+                    st4c(LG_MAP_SDF, c_zero); st4c(LG_MAP_APPROACH, c_zero); st4c(LG_MAP_FLATNESS, c_flat);
+                    st4c(LG_MAP_ISOLATION, c_zero); st4c(LG_MAP_ACCESS, c_zero); st4c(LG_MAP_STEM, c_zero);
+                    st4c(LG_MAP_TRADITIONAL, c_trad);
+                    if (!in_win) st4c(LG_MAP_DISTANCE, c_zero);
+                    if (a.valid) {
+                        if (vec) {
+                            __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(a.valid + off));
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (x0 + j < W) a.valid[off + j] = 0;
+                        }
+                    }
+                }
+            }
+            if (t == 0) {   // arg-max key of a tile without valid pixels: score 0, largest flat index (top-k tie rule)
+                const int ymax = min(ty0 + LG_TH, H) - 1, xmax = min(tx0 + LG_TW, W) - 1;
+                a.tilekeys[(size_t)frame * ntile + tile] =
+                    ((unsigned long long)lg_orderable(0.0f) << 32) | (uint32_t)(ymax * W + xmax);
+            }
+            return;
+        }
+    }
+
+    // ---- per-pixel operands of the full path, requested before the stencil phases so their latency overlaps them
     float din_pre[RPT][4];
     unsigned mnib_pre[RPT], snib_pre[RPT];
 #pragma unroll

@@ -19,6 +19,9 @@ SHIM = r'''
 extern "C" int t_orient(const unsigned long long* bits, int H, int W, int WW, double* out) {
     return lg_host_orientation(bits, H, W, WW, out);
 }
+extern "C" int t_orient_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out) {
+    return lg_host_orientation_rows(bits, H, W, WW, y_off, out);
+}
 extern "C" int t_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int c) {
     return lg_host_ellipse_hit(bits, H, W, WW, u, v, c);
 }
@@ -44,6 +47,7 @@ sys.path.insert(0, %r)
 from oracle import lg_oracle as O
 lib = ctypes.CDLL(%r)
 lib.t_orient.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+lib.t_orient_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 lib.t_hit.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6
 rng = np.random.default_rng(11)
 bad = []
@@ -78,6 +82,16 @@ for case in range(120):
         got = [out[i] for i in range(5)]
         if not np.allclose(got, ref[:5], rtol=1e-12, atol=1e-9):
             bad.append((case, H, W, kind, got, ref[:5]))
+    # the product only ships the bounding-box rows to the host: the band analysis (absolute coordinates) must give
+    # the whole-image answer bit for bit, also where two candidate rectangles tie in area
+    rows = np.nonzero(m.any(axis=1))[0]
+    if rows.size:
+        y0, y1 = int(rows.min()), int(rows.max())
+        band = bits[y0:y1 + 1].copy()
+        out2 = (ctypes.c_double * 5)()
+        ok2 = lib.t_orient_rows(band.ctypes.data, y1 - y0 + 1, W, WW, y0, out2)
+        if ok2 != ok or [out2[i] for i in range(5)] != [out[i] for i in range(5)]:
+            bad.append((case, "band", [out2[i] for i in range(5)], [out[i] for i in range(5)]))
     # clearance probes == brute-force dilation lookup
     dil = O.dilate(m, O.ellipse_se(11))
     for _ in range(20):
