@@ -50,6 +50,28 @@ def make_frames(B, H, W, n_distinct=4):
     return m, d, P
 
 
+def final_kernel_bytes(masks_np, wins, H, W, tile_w=64, tile_h=16):
+    """Compulsory HBM bytes of ONE lg_final_kernel launch for these masks.  Per 64x16 tile:
+      full path  : read depth 4 + mask/stem bits 0.25 + distance_map 4 (inside the sweep window) ; write 7 planes 28 +
+                   valid 1 (+ distance_map 4 outside the window)                                   = 37.25 B/px
+      fast path  : (no mask bit within the stencil reach) write 7 planes 28 + valid 1 (+ distance_map 4 outside the
+                   window), read mask bits 0.125                                                 = 33.125 / 29.125 B/px
+    `wins[i]` = (x0, x1, y0, y1) sweep window of frame i as reported by the library (lg_debug_dt_max)."""
+    total = 0.0
+    for m, (wx0, wx1, wy0, wy1) in zip(masks_np, wins):
+        for ty0 in range(0, H, tile_h):
+            r0, r1 = max(0, ty0 - 3), min(H, ty0 + tile_h + 3)
+            rows_any = m[r0:r1].any(axis=0)
+            for tx0 in range(0, W, tile_w):
+                px = (min(H, ty0 + tile_h) - ty0) * (min(W, tx0 + tile_w) - tx0)
+                in_win = wx0 <= tx0 < wx1 and wy0 <= ty0 < wy1
+                if rows_any[max(0, tx0 - 8):min(W, tx0 + tile_w + 8)].any():
+                    total += 37.25 * px
+                else:
+                    total += (29.125 if in_win else 33.125) * px
+    return total
+
+
 def cpu_baseline(H, W, P, params, n_frames):
     """Restated reference-equivalent CPU path (oracle, NumPy/torch-CPU + C chamfer): same work as
     scripts/utils/grasp_point_selector.py::select_grasp_point.  NOT the reference's own timing
@@ -223,7 +245,13 @@ def main():
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items()},
         }
         if "final" in kern:
-            achieved = FINAL_BYTES_PER_PX * px / (kern["final"]["avg_ms"] * 1e-3) / 1e9
+            # algorithmic bytes of THIS launch: tiles without a leaf pixel in stencil reach take the constant-store path
+            # (no depth read); dense figure (every tile on the full path) = 37.25 B/px
+            n_distinct = min(B, 4)
+            wins = [sels[0].dt_maxima(i)[2] for i in range(n_distinct)]
+            per_distinct = [final_kernel_bytes(masks_np[i:i + 1], wins[i:i + 1], H, W) for i in range(n_distinct)]
+            launch_bytes = sum(per_distinct[i % n_distinct] for i in range(B))
+            achieved = launch_bytes / (kern["final"]["avg_ms"] * 1e-3) / 1e9
             # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
             # + WRITE_SIZE), recorded per pixel in profiles/ by tools/pmc_final.sh; scaled to this launch.
             traffic = None
@@ -234,8 +262,8 @@ def main():
                 traffic = None
             out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "bytes_per_launch": round(FINAL_BYTES_PER_PX * px),
-                               "bytes_per_px": FINAL_BYTES_PER_PX}
+                               "traffic": traffic, "bytes_per_launch": round(launch_bytes),
+                               "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX}
         if "cnn" in kern and not args.no_cnn:
             # MFMA flops actually executed per 9x32x32 patch: layer 0 direct (K = 9 taps x 10 padded channels),
             # layers 1..5 Winograd F(2x2,3x3) = 16 positions x 2 x Cout x Cin x tiles (2.25x fewer than direct).

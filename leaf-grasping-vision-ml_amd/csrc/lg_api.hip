@@ -434,16 +434,9 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     return LG_OK;
 }
 
-// stem bits, forward + backward distance sweeps
+// forward + backward distance sweeps, frame-border maxima, stem bits
 int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
-    {
-        LgSeSpans se;
-        lg_make_se_spans(pl.P.stem_se, &se);
-        ProfScope ps(h, "stem", s);
-        lg_launch_stem_bits(h->bits + off * words, h->stem + off * words, n, pl.H, pl.W, pl.WW,
-                            pl.H - pl.H / pl.P.stem_bottom_div, se, s);
-    }
     {
         ProfScope ps(h, "dt_fwd", s);
         if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, h->win + off, n,
@@ -458,6 +451,15 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     {
         ProfScope ps(h, "dt_border", s);
         lg_launch_dout_border(h->bits + off * words, h->win + off, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, pl.WW, s);
+    }
+    // the stem bits are only read by the fused plane kernel: after the sweeps, when the bit-row export (which slows every
+    // concurrent memory-bound kernel 4x) has drained
+    {
+        LgSeSpans se;
+        lg_make_se_spans(pl.P.stem_se, &se);
+        ProfScope ps(h, "stem", s);
+        lg_launch_stem_bits(h->bits + off * words, h->stem + off * words, n, pl.H, pl.W, pl.WW,
+                            pl.H - pl.H / pl.P.stem_bottom_div, se, s);
     }
     return LG_OK;
 }
