@@ -327,25 +327,34 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
         if (c + 1 < NC) issue_input(c + 1, (c + 1) & 1);
         {   // V = B^T d B for (tci, tau)
             const float* sp = s_mem + (c & 1) * (NIN * 256) + tsrc;
-            float d[4][4];
+            // packed-f32 form: rows as (lo, hi) pairs; the column step folds its negations / half selections into
+            // v_pk_add_f32 modifiers instead of moves
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 dl[4], dh[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 // plain float reads (merged into ds_read2_b64): a float2-typed read makes hipcc drain vmcnt, i.e. the
                 // next chunk's global_load_lds prefetch, in front of it
-                d[i][0] = sp[i * RW]; d[i][1] = sp[i * RW + 1]; d[i][2] = sp[i * RW + 2]; d[i][3] = sp[i * RW + 3];
+                dl[i] = (f32x2){sp[i * RW], sp[i * RW + 1]};
+                dh[i] = (f32x2){sp[i * RW + 2], sp[i * RW + 3]};
             }
-            float r[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                r[0][j] = d[0][j] - d[2][j];
-                r[1][j] = d[1][j] + d[2][j];
-                r[2][j] = d[2][j] - d[1][j];
-                r[3][j] = d[1][j] - d[3][j];
-            }
+            f32x2 tl[4], th[4];
+            tl[0] = dl[0] - dl[2]; th[0] = dh[0] - dh[2];
+            tl[1] = dl[1] + dl[2]; th[1] = dh[1] + dh[2];
+            tl[2] = dl[2] - dl[1]; th[2] = dh[2] - dh[1];
+            tl[3] = dl[1] - dl[3]; th[3] = dh[1] - dh[3];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                f32x4 v = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
-                *reinterpret_cast<f32x4*>(tdst + 4 * i) = v;
+                // column step in two instructions per row (hipcc does not fold the half selections into op_sel itself):
+                //   v01 = (t0 - t2, t1 + t2): src1 = th.lo for both lanes, negated in the low lane
+                //   v23 = (t2 - t1, t1 - t3): src0 = th, src1 = tl.hi for both lanes; low lane -src1, high lane -src0
+                f32x2 v01, v23;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
+                    : "=v"(v01) : "v"(tl[i]), "v"(th[i]));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
+                    : "=v"(v23) : "v"(th[i]), "v"(tl[i]));
+                *reinterpret_cast<f32x2*>(tdst + 4 * i) = v01;
+                *reinterpret_cast<f32x2*>(tdst + 4 * i + 2) = v23;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V visible; does not drain the prefetches
