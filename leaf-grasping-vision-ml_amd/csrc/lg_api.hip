@@ -473,10 +473,10 @@ void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
     parallel_for(h, n, [=](int i) {
         const int b = off + i;
         double o[5];
-        // only the rows of the bounding box are on the host: analyse them as a sub-image (the rest is all zero)
+        // only the rows / words of the bounding box are on the host: analyse them as a band (the rest is all zero)
         const LgWin& w = wh[b];
         const int hy = w.by1 - w.by0 + 1;
-        int ok = hy > 0 ? lg_host_orientation_rows(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, w.by0, o) : 0;
+        int ok = hy > 0 ? lg_host_orientation_band(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, w.by0, w.bx0 >> 6, w.bx1 >> 6, o) : 0;
         LgFrameParams f;
         f.has_angle = ok;
         f.theta = ok ? (float)o[0] : NAN;
@@ -867,7 +867,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
             const int u = (int)((tx * (double)P.f / tz) + (double)P.cx);
             const int v = (int)((ty * (double)P.f / tz) + (double)P.cy);
             if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
-            if (!(hy > 0 && lg_host_ellipse_hit_se(hb, hy, W, WW, u, v - bw.by0, pre_se))) {
+            if (!(hy > 0 && lg_host_ellipse_hit_band(hb, hy, W, WW, bw.bx0 >> 6, bw.bx1 >> 6, u, v - bw.by0, pre_se))) {
                 const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
                 if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
             }

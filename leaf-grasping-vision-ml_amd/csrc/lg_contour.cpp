@@ -22,9 +22,12 @@ namespace {
 struct Run { int y, x0, x1, parent; };  // inclusive span
 struct P2 { long long x, y; };
 
-inline bool bit_at(const unsigned long long* bits, int H, int W, int WW, int x, int y) {
+// only the words [w0, w1] of a row are valid (the host image holds the bounding box of the leaf, everything else is 0)
+inline bool bit_at(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int x, int y) {
     if (x < 0 || y < 0 || x >= W || y >= H) return false;
-    return (bits[(size_t)y * WW + (x >> 6)] >> (x & 63)) & 1ull;
+    const int w = x >> 6;
+    if (w < w0 || w > w1) return false;
+    return (bits[(size_t)y * WW + w] >> (x & 63)) & 1ull;
 }
 
 int find_root(std::vector<Run>& r, int i) {
@@ -37,13 +40,13 @@ int find_root(std::vector<Run>& r, int i) {
 
 // Shoelace area of the 8-connected outer border that starts at (sx, sy) (top-most/left-most pixel
 // of its component), traced through pixel centres like Suzuki-Abe border following.
-double outer_border_area(const unsigned long long* bits, int H, int W, int WW, int sx, int sy) {
+double outer_border_area(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int sx, int sy) {
     // neighbours clockwise (screen coordinates, y down) starting at West
     static const int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
     static const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
     int first = -1;
     for (int k = 0; k < 8; k++)
-        if (bit_at(bits, H, W, WW, sx + dx[k], sy + dy[k])) { first = k; break; }
+        if (bit_at(bits, H, W, WW, w0, w1, sx + dx[k], sy + dy[k])) { first = k; break; }
     if (first < 0) return 0.0;  // single pixel
     const int fx = sx + dx[first], fy = sy + dy[first];
     long long px = fx, py = fy, cx = sx, cy = sy;
@@ -60,7 +63,7 @@ double outer_border_area(const unsigned long long* bits, int H, int W, int WW, i
         bool found = false;
         for (int k = 1; k <= 8; k++) {
             int d = (dprev - k) & 7;  // counter-clockwise from the previous pixel
-            if (bit_at(bits, H, W, WW, (int)cx + dx[d], (int)cy + dy[d])) {
+            if (bit_at(bits, H, W, WW, w0, w1, (int)cx + dx[d], (int)cy + dy[d])) {
                 nx = cx + dx[d];
                 ny = cy + dy[d];
                 found = true;
@@ -114,6 +117,11 @@ void lg_make_se_spans(int k, LgSeSpans* out) {
 }
 
 int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW, int u, int v, const LgSeSpans& se) {
+    return lg_host_ellipse_hit_band(bits, H, W, WW, 0, WW - 1, u, v, se);
+}
+
+int lg_host_ellipse_hit_band(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int u, int v,
+                             const LgSeSpans& se) {
     // dilated[v,u] != 0  <=>  some set pixel (u+dx, v+dy) with (dy,dx) in the (2c+1) ellipse
     // (calculate_pre_grasp_point, grasp_point_selector.py:777-779,804); word-wise span tests on the bit rows
     for (int i = 0; i < se.n; i++) {
@@ -122,7 +130,7 @@ int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW,
         int x0 = std::max(u + se.lo[i], 0), x1 = std::min(u + se.hi[i], W - 1);
         if (x0 > x1) continue;
         const unsigned long long* row = bits + (size_t)y * WW;
-        for (int w = x0 >> 6; w <= (x1 >> 6); w++) {
+        for (int w = std::max(x0 >> 6, w0); w <= std::min(x1 >> 6, w1); w++) {
             unsigned long long m = ~0ull;
             if (w == (x0 >> 6)) m &= ~0ull << (x0 & 63);
             if (w == (x1 >> 6)) m &= ~0ull >> (63 - (x1 & 63));
@@ -139,13 +147,17 @@ int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, in
 }
 
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out) {
-    return lg_host_orientation_rows(bits, H, W, WW, 0, out);
+    return lg_host_orientation_band(bits, H, W, WW, 0, 0, WW - 1, out);
 }
 
-// Same analysis on a band of rows: `bits` points at image row y_off and H is the band height (every other row of the
-// image is empty).  Hull and rectangle are computed in ABSOLUTE image coordinates, so ties between candidate rectangles
-// (decided by the last bits of double arithmetic) fall exactly as they do for the whole image.
 int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out) {
+    return lg_host_orientation_band(bits, H, W, WW, y_off, 0, WW - 1, out);
+}
+
+// Same analysis on a band of rows and words: `bits` points at image row y_off, H is the band height and only the words
+// [w0, w1] of a row are read (every other pixel of the image is empty).  Hull and rectangle are computed in ABSOLUTE image coordinates, so ties between candidate rectangles
+// (decided by the last bits of double arithmetic) fall exactly as they do for the whole image.
+int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int WW, int y_off, int w0, int w1, double* out) {
     std::vector<Run> runs;
     std::vector<int> row_start(H + 1, 0);
     // ---- runs per row
@@ -154,7 +166,7 @@ int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int W
         const unsigned long long* row = bits + (size_t)y * WW;
         bool in = false;
         int start = 0;
-        for (int w = 0; w < WW; w++) {
+        for (int w = w0; w <= w1; w++) {
             unsigned long long v = row[w];
             if (w == WW - 1 && (W & 63)) v &= (~0ull) >> (64 - (W & 63));  // ignore padding bits past W
             // transitions inside the word: bit b of tr is set when pixel b differs from pixel b-1
@@ -167,7 +179,7 @@ int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int W
                 else { in = false; runs.push_back({y, start, x - 1, (int)runs.size()}); }
             }
         }
-        if (in) runs.push_back({y, start, W - 1, (int)runs.size()});
+        if (in) runs.push_back({y, start, std::min(W - 1, 64 * (w1 + 1) - 1), (int)runs.size()});
     }
     row_start[H] = (int)runs.size();
     if (runs.empty()) return 0;
@@ -190,7 +202,7 @@ int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int W
     if (roots.size() > 1) {
         double best_area = -1.0;
         for (int r : roots) {
-            double a = outer_border_area(bits, H, W, WW, runs[r].x0, runs[r].y);
+            double a = outer_border_area(bits, H, W, WW, w0, w1, runs[r].x0, runs[r].y);
             if (a > best_area) { best_area = a; best_root = r; }
         }
     }
@@ -224,17 +236,23 @@ int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int W
         return 1;
     }
     double min_area = 1e300, bw = 0, bh = 0, bang = 0, bcx = 0, bcy = 0;
+    // structure-of-arrays copy of the hull: the O(nh^2) projection loop below is the hot spot of the host hand-off
+    // (nh ~ 150 at 1080p) and vectorises in this form; same expressions, same values
+    std::vector<double> hx(nh), hy(nh);
+    for (int j = 0; j < nh; j++) { hx[j] = (double)hull[j].x; hy[j] = (double)hull[j].y; }
     for (int i = 0; i < nh; i++) {
         const P2 p = hull[i], q = hull[(i + 1) % nh];
         double ex = (double)(q.x - p.x), ey = (double)(q.y - p.y), len = sqrt(ex * ex + ey * ey);
         if (len == 0) continue;
         double ux = ex / len, uy = ey / len;
         double smin = 1e300, smax = -1e300, tmin = 1e300, tmax = -1e300;
+        const double* __restrict__ px = hx.data();
+        const double* __restrict__ py = hy.data();
         for (int j = 0; j < nh; j++) {
-            double s = hull[j].x * ux + hull[j].y * uy;
-            double t = -hull[j].x * uy + hull[j].y * ux;
-            smin = std::min(smin, s); smax = std::max(smax, s);
-            tmin = std::min(tmin, t); tmax = std::max(tmax, t);
+            const double s = px[j] * ux + py[j] * uy;
+            const double t = -px[j] * uy + py[j] * ux;
+            smin = s < smin ? s : smin; smax = s > smax ? s : smax;
+            tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax;
         }
         double area = (smax - smin) * (tmax - tmin);
         if (area < min_area) {

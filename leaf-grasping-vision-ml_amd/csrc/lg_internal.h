@@ -102,7 +102,11 @@ void lg_launch_gather(const float* depth, const uint8_t* mask, const float* cons
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out);
 // the same on the band of rows [y_off, y_off + H) (bits -> row y_off); results in absolute image coordinates
 int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out);
+// ... and reading only the words [w0, w1] of every row (all other pixels are empty)
+int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int WW, int y_off, int w0, int w1, double* out);
 // 1 if any set bit of `bits` lies under the (2c+1)^2 ellipse centred at (u,v)  (pre-grasp clearance probe)
 int lg_host_ellipse_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int clearance);
 int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW, int u, int v, const LgSeSpans& se);
+int lg_host_ellipse_hit_band(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int u, int v,
+                             const LgSeSpans& se);
 void lg_make_se_spans(int k, LgSeSpans* out);

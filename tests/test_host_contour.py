@@ -22,6 +22,14 @@ extern "C" int t_orient(const unsigned long long* bits, int H, int W, int WW, do
 extern "C" int t_orient_rows(const unsigned long long* bits, int H, int W, int WW, int y_off, double* out) {
     return lg_host_orientation_rows(bits, H, W, WW, y_off, out);
 }
+extern "C" int t_orient_band(const unsigned long long* bits, int H, int W, int WW, int y_off, int w0, int w1, double* out) {
+    return lg_host_orientation_band(bits, H, W, WW, y_off, w0, w1, out);
+}
+extern "C" int t_hit_band(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int u, int v, int c) {
+    LgSeSpans se;
+    lg_make_se_spans(2 * c + 1, &se);
+    return lg_host_ellipse_hit_band(bits, H, W, WW, w0, w1, u, v, se);
+}
 extern "C" int t_hit(const unsigned long long* bits, int H, int W, int WW, int u, int v, int c) {
     return lg_host_ellipse_hit(bits, H, W, WW, u, v, c);
 }
@@ -48,6 +56,8 @@ from oracle import lg_oracle as O
 lib = ctypes.CDLL(%r)
 lib.t_orient.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 lib.t_orient_rows.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+lib.t_orient_band.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_double)]
+lib.t_hit_band.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 8
 lib.t_hit.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6
 rng = np.random.default_rng(11)
 bad = []
@@ -92,6 +102,21 @@ for case in range(120):
         ok2 = lib.t_orient_rows(band.ctypes.data, y1 - y0 + 1, W, WW, y0, out2)
         if ok2 != ok or [out2[i] for i in range(5)] != [out[i] for i in range(5)]:
             bad.append((case, "band", [out2[i] for i in range(5)], [out[i] for i in range(5)]))
+        # ... and only the 64-bit words of the bounding box are valid on the host: poison every other word
+        cols = np.nonzero(m.any(axis=0))[0]
+        w0, w1 = int(cols.min()) >> 6, int(cols.max()) >> 6
+        poisoned = band.copy()
+        poisoned[:, :w0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        poisoned[:, w1 + 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        out3 = (ctypes.c_double * 5)()
+        ok3 = lib.t_orient_band(poisoned.ctypes.data, y1 - y0 + 1, W, WW, y0, w0, w1, out3)
+        if ok3 != ok or [out3[i] for i in range(5)] != [out[i] for i in range(5)]:
+            bad.append((case, "words", [out3[i] for i in range(5)], [out[i] for i in range(5)]))
+        for _ in range(10):
+            u, v = int(rng.integers(0, W)), int(rng.integers(0, H))
+            want = lib.t_hit(bits.ctypes.data, H, W, WW, u, v, 5)
+            if lib.t_hit_band(poisoned.ctypes.data, y1 - y0 + 1, W, WW, w0, w1, u, v - y0, 5) != want:
+                bad.append((case, "hit band", u, v))
     # clearance probes == brute-force dilation lookup
     dil = O.dilate(m, O.ellipse_se(11))
     for _ in range(20):
