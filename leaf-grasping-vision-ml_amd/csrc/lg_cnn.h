@@ -13,8 +13,13 @@ struct LgCnn {
     float* wconv[6] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded
     float* bconv[6] = {nullptr};
     float* uwino[6] = {nullptr};  // Winograd F(2x2,3x3) weights [cin][cout][16] (layers 1..5)
-    float* att_w = nullptr;       // [256]
+    float* att_w = nullptr;       // [256] spatial attention (1x1 conv 256 -> 1)
     float att_b = 0.f;
+    int att_type = 0;             // LG_ATT_*
+    float* ca_w1 = nullptr;       // channel attention: [16][256], [16], [256][16], [256]
+    float* ca_b1 = nullptr;
+    float* ca_w2 = nullptr;
+    float* ca_b2 = nullptr;
     float* fcw[4] = {nullptr};    // transposed [in][out], BN folded (first three)
     float* fcb[4] = {nullptr};
     float* act[2] = {nullptr, nullptr};  // ping-pong activation planes, capN patches each

@@ -640,10 +640,15 @@ __global__ __launch_bounds__(512, 1) void lg_wino_ws_kernel(const float* __restr
     }
 }
 
-// attention (1x1 conv 256->1 + sigmoid), global average pool, classifier 256->256->128->64->1 (BN folded).
-// model.py:32-36,63-84,108-128.  One workgroup per patch.
-__global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, const float* __restrict__ att_w,
-                                                      float att_b, const float* __restrict__ w0,
+// attention, global average pool, classifier 256->256->128->64->1 (BN folded).  model.py:30-60,63-84,108-128.
+//   spatial: x * sigmoid(conv1x1(x) 256->1)            channel: x * sigmoid(W2 relu(W1 gap(x) + b1) + b2)
+//   hybrid : x * spatial(x) * channel(x)                none   : x
+// One workgroup per patch, thread t = channel t holding its 16 pixels.
+__global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, int att_type,
+                                                      const float* __restrict__ att_w, float att_b,
+                                                      const float* __restrict__ ca_w1, const float* __restrict__ ca_b1,
+                                                      const float* __restrict__ ca_w2, const float* __restrict__ ca_b2,
+                                                      const float* __restrict__ w0,
                                                       const float* __restrict__ b0, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, const float* __restrict__ w3,
@@ -658,23 +663,53 @@ __global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ 
         float4 x = *reinterpret_cast<const float4*>(hn + t * 16 + 4 * q);
         v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
     }
-    const float aw = att_w[t];
+    const bool spatial = att_type == LG_ATT_SPATIAL || att_type == LG_ATT_HYBRID;
+    const bool channel = att_type == LG_ATT_CHANNEL || att_type == LG_ATT_HYBRID;
+    float f = 0.0f;   // mean over the pixels of x (* spatial attention)
+    if (spatial) {
+        const float aw = att_w[t];
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-        float s = aw * v[p];
+        for (int p = 0; p < 16; p++) {
+            float s = aw * v[p];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) s_a[wave][p] = s;
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) s_a[wave][p] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            float z = s_a[0][p] + s_a[1][p] + s_a[2][p] + s_a[3][p] + att_b;
+            float a = 1.0f / (1.0f + expf(-z));
+            f += v[p] * a;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; p++) f += v[p];
     }
-    __syncthreads();
-    float f = 0.0f;
+    f *= (1.0f / 16.0f);
+    if (channel) {   // squeeze-and-excitation on the un-attended x: gap -> 16 -> 256 -> sigmoid
+        float g = 0.0f;
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-        float z = s_a[0][p] + s_a[1][p] + s_a[2][p] + s_a[3][p] + att_b;
-        float a = 1.0f / (1.0f + expf(-z));
-        f += v[p] * a;
+        for (int p = 0; p < 16; p++) g += v[p];
+        g *= (1.0f / 16.0f);
+        __syncthreads();   // s_a is reused
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float s = ca_w1[j * 256 + t] * g;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) s_a[wave][j] = s;
+        }
+        __syncthreads();
+        float e = ca_b2[t];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float z = fmaxf(s_a[0][j] + s_a[1][j] + s_a[2][j] + s_a[3][j] + ca_b1[j], 0.0f);
+            e += ca_w2[t * 16 + j] * z;
+        }
+        f *= 1.0f / (1.0f + expf(-e));
     }
-    s_f[t] = f * (1.0f / 16.0f);
+    s_f[t] = f;
     __syncthreads();
     {   // 256 -> 256
         float s = b0[t];
@@ -742,7 +777,7 @@ void launch_wino(const float* in, const LgCnn* c, float* out, int N, hipStream_t
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
     for (int i = 0; i < 6; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); }
-    F(c->att_w);
+    F(c->att_w); F(c->ca_w1); F(c->ca_b1); F(c->ca_w2); F(c->ca_b2);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
     F(c->act[0]); F(c->act[1]);
     c->capN = 0;
@@ -809,12 +844,22 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
             if (rc) return rc;
         }
     }
-    if (!w->att_w || !w->att_b) { *err = "lg_cnn_load: missing attention tensor"; return LG_ERR_INVALID; }
-    {
+    c->att_type = w->attention_type;
+    if (c->att_type < LG_ATT_SPATIAL || c->att_type > LG_ATT_NONE) { *err = "lg_cnn_load: unknown attention_type"; return LG_ERR_INVALID; }
+    if (c->att_type == LG_ATT_SPATIAL || c->att_type == LG_ATT_HYBRID) {
+        if (!w->att_w || !w->att_b) { *err = "lg_cnn_load: missing spatial attention tensor"; return LG_ERR_INVALID; }
         std::vector<float> aw(w->att_w, w->att_w + 256);
         int rc = upload(&c->att_w, aw, err);
         if (rc) return rc;
         c->att_b = w->att_b[0];
+    }
+    if (c->att_type == LG_ATT_CHANNEL || c->att_type == LG_ATT_HYBRID) {
+        if (!w->ca_w1 || !w->ca_b1 || !w->ca_w2 || !w->ca_b2) { *err = "lg_cnn_load: missing channel attention tensor"; return LG_ERR_INVALID; }
+        int rc = upload(&c->ca_w1, std::vector<float>(w->ca_w1, w->ca_w1 + 16 * 256), err);
+        if (!rc) rc = upload(&c->ca_b1, std::vector<float>(w->ca_b1, w->ca_b1 + 16), err);
+        if (!rc) rc = upload(&c->ca_w2, std::vector<float>(w->ca_w2, w->ca_w2 + 256 * 16), err);
+        if (!rc) rc = upload(&c->ca_b2, std::vector<float>(w->ca_b2, w->ca_b2 + 256), err);
+        if (rc) return rc;
     }
     const int dims[5] = {256, 256, 128, 64, 1};
     for (int L = 0; L < 4; L++) {
@@ -902,7 +947,8 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits
     if (wmask & 16) LG_WINO(4, B, A); else launch_conv<4, 4, 1, 4>(B, c, A, N, s);  // 128 -> 256, 8x8
     if (wmask & 32) LG_WINO(5, A, B); else launch_conv<5, 4, 1, 4>(A, c, B, N, s);  // 256 -> 256, pool -> 4x4
 #undef LG_WINO
-    hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_w, c->att_b, c->fcw[0], c->fcb[0], c->fcw[1],
+    hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_type, c->att_w, c->att_b, c->ca_w1, c->ca_b1,
+                       c->ca_w2, c->ca_b2, c->fcw[0], c->fcb[0], c->fcw[1],
                        c->fcb[1], c->fcw[2], c->fcb[2], c->fcw[3], c->fcb[3], logits);
     return LG_OK;
 }

@@ -406,9 +406,9 @@ class RefGraspPointSelector:
 CNN_FILTERS = (64, 128, 256)
 
 
-def cnn_param_shapes(in_channels=9, filters=CNN_FILTERS):
-    """state_dict layout of GraspPointCNN(in_channels=9) default config
-    (scripts/utils/ml_grasp_optimizer/model.py:16-84)."""
+def cnn_param_shapes(in_channels=9, filters=CNN_FILTERS, attention_type="spatial"):
+    """state_dict layout of GraspPointCNN(in_channels=9, attention_type, encoder_filters)
+    (scripts/utils/ml_grasp_optimizer/model.py:16-84; attention variants :30-60)."""
     shapes = {}
     c = in_channels
     for b, f in enumerate(filters):
@@ -419,8 +419,24 @@ def cnn_param_shapes(in_channels=9, filters=CNN_FILTERS):
                 shapes[f"encoder.{b}.{bn}.{s}"] = (f,)
         c = f
     F = filters[-1]
-    shapes["attention.0.weight"] = (1, F, 1, 1)
-    shapes["attention.0.bias"] = (1,)
+
+    def channel(prefix):
+        shapes[f"{prefix}.1.weight"] = (F // 16, F, 1, 1)
+        shapes[f"{prefix}.1.bias"] = (F // 16,)
+        shapes[f"{prefix}.3.weight"] = (F, F // 16, 1, 1)
+        shapes[f"{prefix}.3.bias"] = (F,)
+
+    if attention_type == "spatial":
+        shapes["attention.0.weight"] = (1, F, 1, 1)
+        shapes["attention.0.bias"] = (1,)
+    elif attention_type == "channel":
+        channel("attention")
+    elif attention_type == "hybrid":
+        shapes["spatial_attention.0.weight"] = (1, F, 1, 1)
+        shapes["spatial_attention.0.bias"] = (1,)
+        channel("channel_attention")
+    elif attention_type != "none":
+        raise ValueError(attention_type)
     dims = [F, F, F // 2, F // 4, 1]
     for li, idx in enumerate((0, 4, 8, 12)):
         shapes[f"classifier.{idx}.weight"] = (dims[li + 1], dims[li])
@@ -441,13 +457,13 @@ def _hash_unit(idx, salt):
     return x.astype(np.float64) / 4294967296.0 * 2.0 - 1.0
 
 
-def cnn_closed_form_params(seed=0, in_channels=9):
+def cnn_closed_form_params(seed=0, in_channels=9, attention_type="spatial"):
     """Deterministic closed-form fill (no trained best_model.pth exists in the reference tree,
     SURVEY 8d): integer-hash uniform weights with kaiming-uniform scale, non-trivial BN
     gamma/beta/mean/var so BN folding is exercised.  Logits vary with the input (unlike a
     smooth sin fill, which averages out under global pooling)."""
     params = {}
-    for i, (name, shp) in enumerate(cnn_param_shapes(in_channels).items()):
+    for i, (name, shp) in enumerate(cnn_param_shapes(in_channels, attention_type=attention_type).items()):
         n = int(np.prod(shp))
         base = _hash_unit(np.arange(n), 7919 * (i + 1) + 104729 * seed)
         if name.endswith("running_var"):
@@ -480,7 +496,7 @@ def synthetic_patches(n=20, seed=5):
 
 
 def cnn_forward(params, x, dtype=None):
-    """GraspPointCNN.forward in eval mode (model.py:101-128), default 'spatial' attention.
+    """GraspPointCNN.forward in eval mode (model.py:101-128); the attention variant follows from the keys.
     torch (CPU) functional restatement; x [B,9,32,32] -> logits [B]."""
     import torch
     import torch.nn.functional as F
@@ -496,8 +512,19 @@ def cnn_forward(params, x, dtype=None):
                                  p[f"encoder.{b}.{bn}.weight"], p[f"encoder.{b}.{bn}.bias"], False, 0.0, 1e-5)
                 h = F.relu(h)
             h = F.max_pool2d(h, 2)
-        att = torch.sigmoid(F.conv2d(h, p["attention.0.weight"], p["attention.0.bias"]))
-        h = (h * att).mean(dim=(2, 3))
+        def chan(prefix):   # AdaptiveAvgPool2d(1) -> 1x1 conv -> ReLU -> 1x1 conv -> Sigmoid   (model.py:37-44)
+            g = h.mean(dim=(2, 3), keepdim=True)
+            z = F.relu(F.conv2d(g, p[f"{prefix}.1.weight"], p[f"{prefix}.1.bias"]))
+            return torch.sigmoid(F.conv2d(z, p[f"{prefix}.3.weight"], p[f"{prefix}.3.bias"]))
+
+        if "attention.0.weight" in p:            # 'spatial' (the node's default, grasp_point_selector.py:40)
+            h = h * torch.sigmoid(F.conv2d(h, p["attention.0.weight"], p["attention.0.bias"]))
+        elif "attention.1.weight" in p:          # 'channel'
+            h = h * chan("attention")
+        elif "spatial_attention.0.weight" in p:  # 'hybrid': x * spatial(x) * channel(x)   (model.py:115-119)
+            sp = torch.sigmoid(F.conv2d(h, p["spatial_attention.0.weight"], p["spatial_attention.0.bias"]))
+            h = h * sp * chan("channel_attention")
+        h = h.mean(dim=(2, 3))
         for idx in (0, 4, 8):
             h = F.linear(h, p[f"classifier.{idx}.weight"], p[f"classifier.{idx}.bias"])
             h = F.batch_norm(h, p[f"classifier.{idx + 1}.running_mean"], p[f"classifier.{idx + 1}.running_var"],

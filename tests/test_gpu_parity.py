@@ -2,6 +2,8 @@
 the reference-generated golden vectors, and at BASELINE.json's full sizes.
 Tolerances (BASELINE.json north_star): float planes within 1e-4 relative (atol 1e-6 absorbs exact zeros /
 sign changes); integer outputs (distance-transform fixed point, stem, valid, candidate indices) bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -282,6 +284,18 @@ def test_cnn_winograd_matches_direct(sel, monkeypatch):
     for n in (41, 1, 2, 7):
         np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"ws kernel n {n}")
     monkeypatch.delenv("LG_CNN_WS_KC")
+    sel.clear_cnn()
+
+
+def test_cnn_attention_variants_vs_reference(sel):
+    """The sweep's attention variants (model.py:30-60) through lg_cnn_load / lg_cnn_forward vs the reference's outputs."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_variant_vectors.npz"))
+    x = torch.from_numpy(O.synthetic_patches(int(g["n"]), seed=int(g["x_seed"]))).cuda()
+    for att in ("channel", "hybrid", "none"):
+        sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=1, attention_type=att))
+        got = sel.cnn_forward(x).cpu().numpy()
+        np.testing.assert_allclose(got, g[f"logits_{att}"], rtol=1e-4, atol=1e-5, err_msg=att)
+        np.testing.assert_allclose(got, g[f"logits_f64_{att}"], rtol=1e-4, atol=1e-5, err_msg=att)
     sel.clear_cnn()
 
 

@@ -1,6 +1,8 @@
 """Pin the CPU oracle (oracle/lg_oracle.py) against vectors produced by the reference itself
 (tests/golden/reference_vectors.npz, generator: tests/golden/make_golden.py) and against the known
 answers recorded in SURVEY.md Appendix C."""
+import os
+
 import numpy as np
 import pytest
 
@@ -148,3 +150,13 @@ def test_visibility(golden):
     assert O.visibility_score(e2) == 0.0
     assert O.visibility_score(ellipse_mask(96, 128, 40, 60, 20, 10, 45).astype(bool)) == pytest.approx(
         float(golden["vis"][2]), rel=1e-14)
+
+
+def test_cnn_attention_variants_match_reference():
+    """'channel' / 'hybrid' / 'none' attention (model.py:30-60,108-121): oracle restatement vs the reference module's own
+    outputs (tests/golden/make_golden_cnn_variants.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_variant_vectors.npz"))
+    x = O.synthetic_patches(int(g["n"]), seed=int(g["x_seed"]))
+    for att in ("channel", "hybrid", "none"):
+        p = O.cnn_closed_form_params(seed=1, attention_type=att)
+        np.testing.assert_allclose(O.cnn_forward(p, x), g[f"logits_{att}"], rtol=1e-5, atol=1e-6, err_msg=att)
