@@ -22,6 +22,8 @@
  *   lg_cnn_load / lg_cnn_forward   GraspPointCNN.forward (eval)
  *                      (scripts/utils/ml_grasp_optimizer/model.py:101-128), load_ml_model :43-57
  *   lg_select_grasp    GraspPointSelector.select_grasp_point :184-253 (whole path, batched)
+ *   lg_harvest_patches / lg_negative_masks / lg_leaf_contour   EnhancedGraspDataCollector's patch extraction and
+ *                      negative-region helpers (scripts/utils/ml_grasp_optimizer/data_collector.py:91-173,426-490)
  *   lg_leaf_stats      the per-leaf passes of OptimalLeafSelector.select_optimal_leaf
  *                      (scripts/utils/leaf_scorer.py:32-47,66-71,74-138)
  */
@@ -174,6 +176,26 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
    outer contour, in (0, pi]), major axis, minor axis, centre x, centre y.  Returns LG_OK and *found = 0
    when the mask is empty.  Synchronises `stream`. */
 int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream);
+
+/* ---- training-sample harvesting: EnhancedGraspDataCollector (scripts/utils/ml_grasp_optimizer/data_collector.py)
+   lg_harvest_patches   _extract_patches :91-173 (+ the rot90 of _generate_augmented_samples :250-266): raw 32x32 windows
+                        [y-16,y+16) x [x-16,x+16) of depth / mask / the seven score planes maps[0..6] of ONE frame around
+                        n points xy [n][2] DEVICE, rotated by rot[i] quarter turns (torch.rot90; rot may be NULL).
+                        out_depth, out_mask [n][32][32], out_scores [n][7][32][32] f32 DEVICE; flags [n] int32 DEVICE:
+                        bit 0 non-finite depth, 1 empty mask patch, 2 non-finite score, 3 window outside the frame
+                        (_check_boundaries :83-89; nothing written).
+   lg_negative_masks    the regions negatives are drawn from: tip = (dilate5x5(distance_map) == distance_map) & mask
+                        (_get_tip_points :426-443), stem = the mask's bottom quarter eroded twice by the 5x5 ellipse
+                        (_get_stem_points :445-460); u8 [H][W] DEVICE each.
+   lg_leaf_contour      cv2.findContours(EXTERNAL, CHAIN_APPROX_NONE) + max(contourArea) of _get_edge_points :462-490:
+                        every border pixel of the largest outer contour in tracing order, out_xy [cap][2] int32 HOST;
+                        *n_out = number of points (may exceed cap: only cap are written). */
+int lg_harvest_patches(lg_handle h, const float* depth, const uint8_t* mask, const float* const maps[LG_NUM_MAPS],
+                       int H, int W, int n, const int32_t* xy, const int32_t* rot, float* out_depth, float* out_mask,
+                       float* out_scores, int32_t* flags, void* stream);
+int lg_negative_masks(lg_handle h, const float* distance_map, const uint8_t* mask, int H, int W, uint8_t* out_tip,
+                      uint8_t* out_stem, void* stream);
+int lg_leaf_contour(lg_handle h, const uint8_t* mask, int H, int W, int32_t* out_xy, int cap, int* n_out, void* stream);
 
 /* Per-kernel device timing with HIP events recorded on the launch stream (bench.py roofline).
    lg_profile_enable(h,1) starts collecting for every kernel (an event pair around each launch);

@@ -18,6 +18,7 @@ try:
     from .leaf_scorer import OptimalLeafSelector  # noqa: F401
     from .hybrid_grasp_selector import HybridGraspSelector  # noqa: F401
     from .node_harness import LeafGraspHarness  # noqa: F401
-    __all__ += ["OptimalLeafSelector", "HybridGraspSelector", "LeafGraspHarness"]
+    from .data_collector import EnhancedGraspDataCollector  # noqa: F401
+    __all__ += ["OptimalLeafSelector", "HybridGraspSelector", "LeafGraspHarness", "EnhancedGraspDataCollector"]
 except ImportError:  # modules of later build steps
     pass

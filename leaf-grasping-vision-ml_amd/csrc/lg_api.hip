@@ -611,6 +611,55 @@ int lg_gather_patches(lg_handle h, const float* depth, const uint8_t* mask, cons
     return LG_OK;
 }
 
+int lg_harvest_patches(lg_handle h, const float* depth, const uint8_t* mask, const float* const maps[LG_NUM_MAPS], int H,
+                       int W, int n, const int32_t* xy, const int32_t* rot, float* out_depth, float* out_mask,
+                       float* out_scores, int32_t* flags, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!depth || !mask || !maps || !xy || !out_depth || !out_mask || !out_scores || !flags || n < 1 || H < 32 || W < 32)
+        return fail(h, LG_ERR_INVALID, "lg_harvest_patches: bad argument");
+    for (int i = 0; i < 7; i++)
+        if (!maps[i]) return fail(h, LG_ERR_INVALID, "lg_harvest_patches: maps[0..6] are required");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    lg_launch_harvest(depth, mask, maps, H, W, n, xy, rot, out_depth, out_mask, out_scores, flags, s);
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_negative_masks(lg_handle h, const float* distance_map, const uint8_t* mask, int H, int W, uint8_t* out_tip,
+                      uint8_t* out_stem, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!distance_map || !mask || !out_tip || !out_stem || H < 1 || W < 1)
+        return fail(h, LG_ERR_INVALID, "lg_negative_masks: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 1, H, W, 20);
+    if (rc) return rc;
+    // scratch for the first erosion: the u8 view of the forward-sweep workspace (H*W bytes needed, 8*H*W available)
+    lg_launch_negative_masks(distance_map, mask, out_tip, out_stem, reinterpret_cast<uint8_t*>(h->tmp), H, W, s);
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_leaf_contour(lg_handle h, const uint8_t* mask, int H, int W, int32_t* out_xy, int cap, int* n_out, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!mask || !n_out || (cap > 0 && !out_xy) || cap < 0 || H < 1 || W < 1)
+        return fail(h, LG_ERR_INVALID, "lg_leaf_contour: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 1, H, W, 20);
+    if (rc) return rc;
+    const int WW = (W + 63) / 64;
+    lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
+    LG_HIP(h, hipMemcpyAsync(h->bits_host, h->bits, sizeof(unsigned long long) * (size_t)H * WW, hipMemcpyDeviceToHost, s));
+    LG_HIP(h, hipStreamSynchronize(s));
+    std::vector<int> pts;
+    const int n = lg_host_contour_points(h->bits_host, H, W, WW, pts);
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; i++) { out_xy[2 * i] = pts[2 * i]; out_xy[2 * i + 1] = pts[2 * i + 1]; }
+    return LG_OK;
+}
+
 int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream_) {
     if (!h) return LG_ERR_INVALID;
     if (!mask || !out || !found || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_leaf_orientation: bad argument");

@@ -40,14 +40,18 @@ int find_root(std::vector<Run>& r, int i) {
 
 // Shoelace area of the 8-connected outer border that starts at (sx, sy) (top-most/left-most pixel
 // of its component), traced through pixel centres like Suzuki-Abe border following.
-double outer_border_area(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int sx, int sy) {
+double outer_border_area(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int sx, int sy,
+                         std::vector<int>* rec = nullptr) {
     // neighbours clockwise (screen coordinates, y down) starting at West
     static const int dx[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
     static const int dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
     int first = -1;
     for (int k = 0; k < 8; k++)
         if (bit_at(bits, H, W, WW, w0, w1, sx + dx[k], sy + dy[k])) { first = k; break; }
-    if (first < 0) return 0.0;  // single pixel
+    if (first < 0) {  // single pixel
+        if (rec) { rec->push_back(sx); rec->push_back(sy); }
+        return 0.0;
+    }
     const int fx = sx + dx[first], fy = sy + dy[first];
     long long px = fx, py = fy, cx = sx, cy = sy;
     double acc = 0.0;
@@ -72,6 +76,7 @@ double outer_border_area(const unsigned long long* bits, int H, int W, int WW, i
         }
         if (have_last) acc += (double)lastx * (double)cy - (double)cx * (double)lasty;
         lastx = cx; lasty = cy; have_last = true;
+        if (rec) { rec->push_back((int)cx); rec->push_back((int)cy); }
         if (!found) break;
         if (nx == sx && ny == sy && cx == fx && cy == fy) break;
         px = cx; py = cy; cx = nx; cy = ny;
@@ -157,8 +162,9 @@ int lg_host_orientation_rows(const unsigned long long* bits, int H, int W, int W
 // Same analysis on a band of rows and words: `bits` points at image row y_off, H is the band height and only the words
 // [w0, w1] of a row are read (every other pixel of the image is empty).  Hull and rectangle are computed in ABSOLUTE image coordinates, so ties between candidate rectangles
 // (decided by the last bits of double arithmetic) fall exactly as they do for the whole image.
-int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int WW, int y_off, int w0, int w1, double* out) {
-    std::vector<Run> runs;
+// runs of the band + the root run of the component with the largest outer contour (cv2.findContours EXTERNAL +
+// max(contourArea)); returns -1 for an empty band
+static int lg_best_component(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, std::vector<Run>& runs) {
     std::vector<int> row_start(H + 1, 0);
     // ---- runs per row
     for (int y = 0; y < H; y++) {
@@ -182,7 +188,7 @@ int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int W
         if (in) runs.push_back({y, start, std::min(W - 1, 64 * (w1 + 1) - 1), (int)runs.size()});
     }
     row_start[H] = (int)runs.size();
-    if (runs.empty()) return 0;
+    if (runs.empty()) return -1;
     // ---- union runs that touch (8-connectivity: overlap after growing by one pixel)
     for (int y = 1; y < H; y++) {
         int a = row_start[y - 1], ae = row_start[y], b = row_start[y], be = row_start[y + 1];
@@ -206,6 +212,13 @@ int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int W
             if (a > best_area) { best_area = a; best_root = r; }
         }
     }
+    return best_root;
+}
+
+int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int WW, int y_off, int w0, int w1, double* out) {
+    std::vector<Run> runs;
+    const int best_root = lg_best_component(bits, H, W, WW, w0, w1, runs);
+    if (best_root < 0) return 0;
     // ---- hull of the component's run end points (Andrew monotone chain, same orientation/ordering
     //      convention as the documented spec: sort by x then y, counter-clockwise, collinear dropped)
     std::vector<P2> pts;
@@ -274,4 +287,16 @@ int lg_host_orientation_band(const unsigned long long* bits, int H, int W, int W
     out[3] = bcx;
     out[4] = bcy;
     return 1;
+}
+
+// Outer contour of the component with the largest contour area, every border pixel in tracing order (cv2.findContours
+// RETR_EXTERNAL / CHAIN_APPROX_NONE restated: start at the component's top-most, then left-most pixel, first look from
+// the West neighbour clockwise, then walk counter-clockwise from the previous pixel).  xy receives x0,y0,x1,y1,...
+int lg_host_contour_points(const unsigned long long* bits, int H, int W, int WW, std::vector<int>& xy) {
+    std::vector<Run> runs;
+    xy.clear();
+    const int best_root = lg_best_component(bits, H, W, WW, 0, WW - 1, runs);
+    if (best_root < 0) return 0;
+    outer_border_area(bits, H, W, WW, 0, WW - 1, runs[best_root].x0, runs[best_root].y, &xy);
+    return (int)(xy.size() / 2);
 }

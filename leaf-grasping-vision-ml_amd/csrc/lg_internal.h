@@ -110,3 +110,13 @@ int lg_host_ellipse_hit_se(const unsigned long long* bits, int H, int W, int WW,
 int lg_host_ellipse_hit_band(const unsigned long long* bits, int H, int W, int WW, int w0, int w1, int u, int v,
                              const LgSeSpans& se);
 void lg_make_se_spans(int k, LgSeSpans* out);
+#ifdef __cplusplus
+#include <vector>
+// outer contour (all border pixels, tracing order) of the component with the largest contour area; returns #points
+int lg_host_contour_points(const unsigned long long* bits, int H, int W, int WW, std::vector<int>& xy);
+#endif
+void lg_launch_harvest(const float* depth, const uint8_t* mask, const float* const* maps_host, int H, int W, int n,
+                       const int32_t* xy, const int32_t* rot, float* out_depth, float* out_mask, float* out_scores,
+                       int32_t* flags, hipStream_t s);
+void lg_launch_negative_masks(const float* dist, const uint8_t* mask, uint8_t* tip, uint8_t* stem, uint8_t* scratch, int H,
+                              int W, hipStream_t s);

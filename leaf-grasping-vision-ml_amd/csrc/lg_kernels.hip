@@ -1257,3 +1257,109 @@ void lg_launch_gather(const float* depth, const uint8_t* mask, const float* cons
     for (int i = 0; i < 7; i++) gm.p[i] = maps_host[i];
     hipLaunchKernelGGL(lg_gather_kernel, dim3(k, B), dim3(256), 0, s, depth, mask, gm, H, W, k, xy, n, patches);
 }
+
+// ============================================================================ training-sample harvesting
+// EnhancedGraspDataCollector (scripts/utils/ml_grasp_optimizer/data_collector.py): raw, un-normalised 32x32 windows
+// [y-16, y+16) x [x-16, x+16) of depth, mask and the seven score planes around n points of ONE frame
+// (_extract_patches :91-173), optionally rotated by rot[i] quarter turns like torch.rot90(t, k, dims=(-2,-1))
+// (_generate_augmented_samples :250-293).  flags[i]: bit 0 non-finite depth, bit 1 empty mask patch, bit 2 non-finite
+// score value, bit 3 window not inside the frame (nothing is written for that point).
+__global__ __launch_bounds__(256) void lg_harvest_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                         LgGatherMaps maps, int H, int W, const int32_t* __restrict__ xy,
+                                                         const int32_t* __restrict__ rot, float* __restrict__ out_depth,
+                                                         float* __restrict__ out_mask, float* __restrict__ out_scores,
+                                                         int32_t* __restrict__ flags) {
+    __shared__ int s_flag, s_any;
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int px = xy[2 * i], py = xy[2 * i + 1];
+    const int k = rot ? (rot[i] & 3) : 0;
+    if (t == 0) { s_flag = 0; s_any = 0; }
+    __syncthreads();
+    if (px < 16 || py < 16 || px + 16 > W || py + 16 > H) {   // _check_boundaries :83-89
+        if (t == 0) flags[i] = 8;
+        return;
+    }
+    int fl = 0, any = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int o = t + 256 * q, r = o >> 5, c = o & 31;
+        // torch.rot90: k=1: out[r][c] = in[c][31-r]; k=2: in[31-r][31-c]; k=3: in[31-c][r]
+        const int sr = k == 0 ? r : k == 1 ? c : k == 2 ? 31 - r : 31 - c;
+        const int sc = k == 0 ? c : k == 1 ? 31 - r : k == 2 ? 31 - c : r;
+        const size_t src = (size_t)(py - 16 + sr) * W + (px - 16 + sc);
+        const float d = depth[src];
+        const float m = mask[src] ? 1.0f : 0.0f;
+        if (!isfinite(d)) fl |= 1;
+        any |= (m != 0.0f);
+        out_depth[(size_t)i * 1024 + o] = d;
+        out_mask[(size_t)i * 1024 + o] = m;
+#pragma unroll
+        for (int ch = 0; ch < 7; ch++) {
+            const float v = maps.p[ch][src];
+            if (!isfinite(v)) fl |= 4;
+            out_scores[((size_t)i * 7 + ch) * 1024 + o] = v;
+        }
+    }
+    if (fl) atomicOr(&s_flag, fl);
+    if (any) atomicOr(&s_any, 1);
+    __syncthreads();
+    if (t == 0) flags[i] = s_flag | (s_any ? 0 : 2);
+}
+
+void lg_launch_harvest(const float* depth, const uint8_t* mask, const float* const* maps_host, int H, int W, int n,
+                       const int32_t* xy, const int32_t* rot, float* out_depth, float* out_mask, float* out_scores,
+                       int32_t* flags, hipStream_t s) {
+    LgGatherMaps gm;
+    for (int i = 0; i < 7; i++) gm.p[i] = maps_host[i];
+    hipLaunchKernelGGL(lg_harvest_kernel, dim3(n), dim3(256), 0, s, depth, mask, gm, H, W, xy, rot, out_depth, out_mask,
+                       out_scores, flags);
+}
+
+// Negative-sample regions (data_collector.py:426-466):
+//   tip  = (cv2.dilate(dist, ones(5,5)) == dist) & mask      local maxima of the distance transform (:430-437)
+//   stem = erode(erode(mask with rows < int(0.75 H) cleared, ellipse 5x5), ellipse 5x5)  (:449-456), iteration `pass`
+// cv2's morphology border is "ignore": a dilation never sees values outside the frame, an erosion is not eroded by it.
+__global__ __launch_bounds__(256) void lg_tip_kernel(const float* __restrict__ dist, const uint8_t* __restrict__ mask,
+                                                     uint8_t* __restrict__ tip, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float d = dist[(size_t)y * W + x];
+    float mx = d;
+    for (int dy = -2; dy <= 2; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; dx++) {
+            const int xx = x + dx;
+            if (xx >= 0 && xx < W) mx = fmaxf(mx, dist[(size_t)yy * W + xx]);
+        }
+    }
+    tip[(size_t)y * W + x] = (mx == d && mask[(size_t)y * W + x]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void lg_erode5_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H,
+                                                        int W, int first_row) {
+    // 5x5 MORPH_ELLIPSE: rows -2 / +2 hold the centre column only, rows -1..1 all five columns; rows < first_row of src
+    // count as background (stem_region[:int(0.75*height)] = 0)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    bool keep = true;
+    for (int dy = -2; dy <= 2 && keep; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int r = (dy == -2 || dy == 2) ? 0 : 2;
+        for (int dx = -r; dx <= r; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            if (yy < first_row || !src[(size_t)yy * W + xx]) { keep = false; break; }
+        }
+    }
+    dst[(size_t)y * W + x] = keep ? 1 : 0;
+}
+
+void lg_launch_negative_masks(const float* dist, const uint8_t* mask, uint8_t* tip, uint8_t* stem, uint8_t* scratch, int H,
+                              int W, hipStream_t s) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4), block(256);
+    hipLaunchKernelGGL(lg_tip_kernel, grid, block, 0, s, dist, mask, tip, H, W);
+    const int first_row = (int)(0.75 * (double)H);   // int(0.75 * height)
+    hipLaunchKernelGGL(lg_erode5_kernel, grid, block, 0, s, mask, scratch, H, W, first_row);
+    hipLaunchKernelGGL(lg_erode5_kernel, grid, block, 0, s, scratch, stem, H, W, 0);
+}

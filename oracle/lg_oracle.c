@@ -318,7 +318,10 @@ static int lg_hull(lg_pt* pts, int n, lg_pt* hull) {
  * out[3]=cx, out[4]=cy, out[5]=contour area, out[6]=contour length (points).
  * Returns 1 if a contour was found, 0 otherwise.
  */
-int lg_leaf_orientation(const uint8_t* mask, int H, int W, double* out) {
+/* Largest external contour (cv2.findContours RETR_EXTERNAL / CHAIN_APPROX_NONE + max(cv2.contourArea)):
+   every border pixel in tracing order, coordinates of the 1-pixel-padded image.  Returns the number of
+   points (0: empty mask); *out_pts is malloc'ed (cap *out_cap), *out_area = shoelace area. */
+static int lg_largest_contour(const uint8_t* mask, int H, int W, lg_pt** out_pts, int* out_cap, double* out_area) {
     const int step = W + 2;
     uint8_t* img = (uint8_t*)calloc((size_t)(H + 2) * step, 1);
     int32_t* lab = (int32_t*)calloc((size_t)(H + 2) * step, sizeof(int32_t));
@@ -381,11 +384,41 @@ int lg_leaf_orientation(const uint8_t* mask, int H, int W, double* out) {
     free(stack);
     free(lab);
     free(img);
+    free(cur);
     if (best_n == 0) {
-        free(cur);
         free(best);
+        *out_pts = NULL;
         return 0;
     }
+    *out_pts = best;
+    *out_cap = cap;
+    *out_area = best_area;
+    return best_n;
+}
+
+/* The points of that contour in image coordinates, tracing order (data_collector.py:464-470 iterates them);
+   returns their number, writes at most cap. */
+int lg_leaf_contour_points(const uint8_t* mask, int H, int W, int32_t* out_xy, int cap) {
+    lg_pt* pts = NULL;
+    int pcap = 0, i;
+    double area = 0.0;
+    const int n = lg_largest_contour(mask, H, W, &pts, &pcap, &area);
+    for (i = 0; i < n && i < cap; i++) {
+        out_xy[2 * i] = pts[i].x - 1;
+        out_xy[2 * i + 1] = pts[i].y - 1;
+    }
+    free(pts);
+    return n;
+}
+
+int lg_leaf_orientation(const uint8_t* mask, int H, int W, double* out) {
+    lg_pt* best = NULL;
+    lg_pt* cur;
+    int cap = 0;
+    double best_area = 0.0;
+    const int best_n = lg_largest_contour(mask, H, W, &best, &cap, &best_area);
+    if (best_n == 0) return 0;
+    cur = (lg_pt*)malloc(sizeof(lg_pt) * cap);
     out[5] = best_area;
     out[6] = (double)best_n;
     {

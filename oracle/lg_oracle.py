@@ -59,6 +59,8 @@ def _lib():
         L.lg_dilate.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int, u8p]
         L.lg_leaf_orientation.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.lg_leaf_orientation.restype = ctypes.c_int
+        L.lg_leaf_contour_points.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+        L.lg_leaf_contour_points.restype = ctypes.c_int
         L.lg_greedy_nms.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
         L.lg_greedy_nms.restype = ctypes.c_int
@@ -107,6 +109,93 @@ def leaf_orientation_raw(mask_u8):
     out = (ctypes.c_double * 8)()
     ok = _lib().lg_leaf_orientation(p, a.shape[0], a.shape[1], out)
     return None if not ok else [out[i] for i in range(7)]
+
+
+def leaf_contour_points(mask_u8):
+    """Points of max(findContours(EXTERNAL, CHAIN_APPROX_NONE), key=contourArea), tracing order -> int32 [n,2] (x,y)."""
+    a, p = _u8(mask_u8)
+    cap = 4 * int(a.sum()) + 16
+    out = np.empty((cap, 2), np.int32)
+    n = _lib().lg_leaf_contour_points(p, a.shape[0], a.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), cap)
+    return out[:n].copy()
+
+
+# --------------------------------------------------------------------------- ml_grasp_optimizer/data_collector.py
+# Restatement of EnhancedGraspDataCollector's geometry helpers (cv2 calls replaced by the stand-ins above: "parity
+# unpinned" vs real OpenCV; the pure-torch / pure-Python helpers are pinned by tests/golden/collector_vectors.npz).
+SCORE_KEYS = ("sdf_score", "approach_score", "flatness_map", "isolation_map", "distance_map", "accessibility_map",
+              "stem_penalty")   # required_scores, data_collector.py:138-140
+
+
+def collector_extract_patches(x, y, mask, depth, scores, patch_size=32, k=0):
+    """_extract_patches (:91-173) + _rotate_tensor (:395-398): raw slices [y-h:y+h, x-h:x+h], rotated k quarter turns.
+    Returns (depth [P,P], mask [P,P] float, scores [7,P,P]) or None like the reference's validation."""
+    h = patch_size // 2
+    H, W = mask.shape
+    if y < h or y >= H - h or x < h or x >= W - h:      # _check_boundaries :83-89 (note: >= H - h excludes y = H - h)
+        return None
+    d = np.asarray(depth)[y - h:y + h, x - h:x + h].astype(np.float32)
+    m = (np.asarray(mask)[y - h:y + h, x - h:x + h] != 0).astype(np.float32)
+    if not np.all(np.isfinite(d)) or not m.any():
+        return None
+    sc = np.stack([np.asarray(scores[kname])[y - h:y + h, x - h:x + h].astype(np.float32) for kname in SCORE_KEYS])
+    if not np.all(np.isfinite(sc)):
+        return None
+    return np.rot90(d, k).copy(), np.rot90(m, k).copy(), np.rot90(sc, k, axes=(-2, -1)).copy()
+
+
+def collector_rotate_point(point, angle, size):
+    """_rotate_point (:400-420), float64 like the reference."""
+    x, y = point
+    c = size // 2
+    a = np.radians(angle)
+    x -= c
+    y -= c
+    nx = x * np.cos(a) - y * np.sin(a)
+    ny = x * np.sin(a) + y * np.cos(a)
+    return int(nx + c), int(ny + c)
+
+
+def collector_tip_points(mask_u8):
+    """_get_tip_points (:426-443): local maxima of the distance transform under a 5x5 box, on the mask; sorted by
+    distance (descending, stable: ties keep row-major order), top quarter."""
+    m = (np.asarray(mask_u8) != 0).astype(np.uint8)
+    dist = distance_transform(m, 5)
+    H, W = m.shape
+    pad = np.full((H + 4, W + 4), -np.inf, np.float32)
+    pad[2:-2, 2:-2] = dist
+    mx = np.max(np.stack([pad[dy:dy + H, dx:dx + W] for dy in range(5) for dx in range(5)]), axis=0)
+    ys, xs = np.where((mx == dist) & (m > 0))
+    pts = list(zip(xs.tolist(), ys.tolist()))
+    pts.sort(key=lambda p: dist[p[1], p[0]], reverse=True)
+    return pts[:max(1, len(pts) // 4)]
+
+
+def collector_stem_points(mask_u8):
+    """_get_stem_points (:445-460): bottom quarter of the mask eroded twice by the 5x5 ellipse."""
+    m = (np.asarray(mask_u8) != 0).astype(np.uint8)
+    H = m.shape[0]
+    m[:int(0.75 * H)] = 0
+    se = ellipse_se(5)
+    for _ in range(2):   # erode = complement of the dilation of the complement (symmetric SE; the frame does not erode)
+        m = (1 - dilate(1 - m, se)).astype(np.uint8)
+    ys, xs = np.where(m > 0)
+    return list(zip(xs.tolist(), ys.tolist()))
+
+
+def collector_edge_points(mask_u8):
+    """_get_edge_points (:462-490): points of the largest outer contour whose turning angle is below 45 degrees."""
+    pts = leaf_contour_points((np.asarray(mask_u8) != 0).astype(np.uint8)).astype(np.int64)
+    n = len(pts)
+    out = []
+    for i in range(n):
+        prev, cur, nxt = pts[i - 1], pts[i], pts[(i + 1) % n]
+        v1, v2 = prev - cur, nxt - cur
+        cross = v1[0] * v2[1] - v1[1] * v2[0]            # np.cross of 2-vectors (deprecated form in the reference)
+        ang = abs(np.arctan2(cross, v1[0] * v2[0] + v1[1] * v2[1]))
+        if ang < np.pi / 4:
+            out.append((int(cur[0]), int(cur[1])))
+    return out
 
 
 # --------------------------------------------------------------------------- image_processor.py
