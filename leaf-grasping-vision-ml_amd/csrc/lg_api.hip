@@ -233,8 +233,8 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->win_host, sizeof(LgWin) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->bits_host, sizeof(unsigned long long) * words));
-    // LG_EXPORT_KERNEL=1 replaces the D2H memcpy by a 32-workgroup zero-copy kernel (measured slower: the sweeps
-    // finish at 2.23 ms vs 1.73 ms with the memcpy on the priority stream); kept for experiments only.
+    // device-side alias of the pinned image: lg_export_rows_kernel posts only the bounding-box bits into it.
+    // LG_EXPORT_MEMCPY=1 (A/B) or an unmapped allocation: whole-batch hipMemcpyAsync instead.
     if (getenv("LG_EXPORT_MEMCPY") || hipHostGetDevicePointer((void**)&h->bits_host_dev, h->bits_host, 0) != hipSuccess)
         h->bits_host_dev = nullptr;   // fall back to a full-batch hipMemcpyAsync
     LG_HIP(h, dev_alloc(&h->cand_xy, (size_t)nB * nK * 2));

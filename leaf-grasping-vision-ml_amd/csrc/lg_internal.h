@@ -77,7 +77,6 @@ struct LgFinalArgs {
 
 // kernel launchers (lg_kernels.hip)
 void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s);
-void lg_launch_export(const unsigned long long* src, unsigned long long* dst_host_devptr, long long nwords, hipStream_t s);
 void lg_launch_export_rows(const unsigned long long* bits, const LgWin* wins, unsigned long long* dst_host_devptr, int B,
                            int H, int WW, hipStream_t s);
 void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,

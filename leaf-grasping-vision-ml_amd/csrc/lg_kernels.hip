@@ -147,26 +147,6 @@ void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, i
     hipLaunchKernelGGL(lg_pack_bits_kernel, dim3(blocks), dim3(256), 0, s, mask, bits, H, W, WW, nwords);
 }
 
-// Export of the bit rows to pinned host memory by a deliberately SMALL grid.  hipMemcpyAsync(D2H) is executed
-// by a blit kernel whose grid fills every CU with waves stalled on PCIe; the distance-transform sweeps (one
-// long-running workgroup per CU) then start ~0.65 ms late (measured, B=128).  32 workgroups of posted 16-byte
-// writes keep PCIe busy and leave the CUs to the sweeps.
-typedef unsigned int lg_u4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void lg_export_kernel(const lg_u4* __restrict__ src, lg_u4* __restrict__ dst_host,
-                                                        long long n16) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
-        dst_host[i] = src[i];
-}
-
-void lg_launch_export(const unsigned long long* src, unsigned long long* dst_host_devptr, long long nwords, hipStream_t s) {
-    long long n16 = nwords / 2;
-    if (n16 > 0)
-        hipLaunchKernelGGL(lg_export_kernel, dim3(32), dim3(256), 0, s, reinterpret_cast<const lg_u4*>(src),
-                           reinterpret_cast<lg_u4*>(dst_host_devptr), n16);
-    if (nwords & 1)  // odd tail word
-        hipMemcpyAsync(dst_host_devptr + nwords - 1, src + nwords - 1, 8, hipMemcpyDeviceToDevice, s);
-}
-
 // Export of the bits the host needs -- the rows and 64-bit words of each frame's bounding box only (a leaf spans a third
 // of the frame in each direction: ~10x less PCIe traffic than the whole batch) -- by posted 8-byte writes into the pinned host image,
 // which keeps its [B][H][WW] layout; rows outside the bounding box are all zero and never read by the host.
