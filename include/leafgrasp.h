@@ -82,14 +82,14 @@ typedef struct lg_params {
     int32_t mask_is_bool;                           /* 1: torch.bool mask => border patches give no ML score */
 } lg_params;
 
-/* Raw GraspPointCNN(in_channels=9, attention_type, [64,128,256]) state_dict tensors, HOST pointers,
+/* Raw GraspPointCNN(in_channels=9, attention_type, encoder_filters) state_dict tensors, HOST pointers,
    float32, PyTorch layouts (conv: [Cout][Cin][3][3], linear: [out][in]); BN is folded at load.
    attention_type (scripts/utils/ml_grasp_optimizer/model.py:30-60): LG_ATT_SPATIAL is what the node
    instantiates (grasp_point_selector.py:40); CHANNEL / HYBRID / NONE are the sweep variants. */
 enum { LG_ATT_SPATIAL = 0, LG_ATT_CHANNEL = 1, LG_ATT_HYBRID = 2, LG_ATT_NONE = 3 };
 typedef struct lg_cnn_weights {
-    const float* conv_w[6];  const float* conv_b[6];       /* encoder.{0,1,2}.{0,3} */
-    const float* bn_g[6]; const float* bn_b[6]; const float* bn_m[6]; const float* bn_v[6]; /* encoder.{b}.{1,4} */
+    const float* conv_w[8];  const float* conv_b[8];       /* encoder.{b}.{0,3}, b < n_blocks (2 per block) */
+    const float* bn_g[8]; const float* bn_b[8]; const float* bn_m[8]; const float* bn_v[8]; /* encoder.{b}.{1,4} */
     const float* att_w; const float* att_b;               /* attention.0 : [1][256][1][1], [1] */
     const float* fc_w[4]; const float* fc_b[4];            /* classifier.{0,4,8,12} */
     const float* fbn_g[3]; const float* fbn_b[3]; const float* fbn_m[3]; const float* fbn_v[3]; /* classifier.{1,5,9} */
@@ -97,6 +97,9 @@ typedef struct lg_cnn_weights {
     int32_t attention_type;                                /* LG_ATT_*; att_w/att_b: SPATIAL, HYBRID (spatial_attention.0) */
     const float* ca_w1; const float* ca_b1;                /* CHANNEL: attention.1, HYBRID: channel_attention.1 : [16][256][1][1], [16] */
     const float* ca_w2; const float* ca_b2;                /*          attention.3,         channel_attention.3 : [256][16][1][1], [256] */
+    int32_t n_blocks;                                      /* 0 = the default encoder [64,128,256]; else 3 or 4 */
+    int32_t filters[4];                                    /* encoder_filters: [32,64,128] [64,128,256] [64,128,256,512] [128,256,512]
+                                                              (train_model_mlflow.py:177-182); attention / classifier sizes follow filters[n_blocks-1] */
 } lg_cnn_weights;
 
 /* Per-frame result of lg_select_grasp (HOST memory). */

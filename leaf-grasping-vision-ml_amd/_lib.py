@@ -27,11 +27,12 @@ _FP = C.POINTER(C.c_float)
 
 
 class LgCnnWeights(C.Structure):
-    _fields_ = [("conv_w", _FP * 6), ("conv_b", _FP * 6), ("bn_g", _FP * 6), ("bn_b", _FP * 6),
-                ("bn_m", _FP * 6), ("bn_v", _FP * 6), ("att_w", _FP), ("att_b", _FP),
+    _fields_ = [("conv_w", _FP * 8), ("conv_b", _FP * 8), ("bn_g", _FP * 8), ("bn_b", _FP * 8),
+                ("bn_m", _FP * 8), ("bn_v", _FP * 8), ("att_w", _FP), ("att_b", _FP),
                 ("fc_w", _FP * 4), ("fc_b", _FP * 4), ("fbn_g", _FP * 3), ("fbn_b", _FP * 3),
                 ("fbn_m", _FP * 3), ("fbn_v", _FP * 3), ("bn_eps", C.c_float), ("attention_type", C.c_int32),
-                ("ca_w1", _FP), ("ca_b1", _FP), ("ca_w2", _FP), ("ca_b2", _FP)]
+                ("ca_w1", _FP), ("ca_b1", _FP), ("ca_w2", _FP), ("ca_b2", _FP),
+                ("n_blocks", C.c_int32), ("filters", C.c_int32 * 4)]
 
 
 class LgGraspResult(C.Structure):

@@ -1,7 +1,8 @@
 """GraspPointCNN weights -> lg_cnn_weights (include/leafgrasp.h).  State-dict layout of
 scripts/utils/ml_grasp_optimizer/model.py::GraspPointCNN(in_channels=9, attention_type, encoder_filters [64,128,256]);
 checkpoint key 'model_state_dict' (grasp_point_selector.py:48-49).  The attention variant ('spatial' = the node's
-default, 'channel', 'hybrid', 'none'; model.py:30-60) is recognised from the keys.  Other encoder_filters are rejected."""
+default, 'channel', 'hybrid', 'none'; model.py:30-60) is recognised from the keys.  encoder_filters: the four configurations of the reference's sweep
+(train_model_mlflow.py:177-182), recognised from the conv shapes."""
 import ctypes as C
 
 import numpy as np
@@ -10,35 +11,58 @@ from ._lib import LgCnnWeights
 
 _FP = C.POINTER(C.c_float)
 
-EXPECTED_SHAPES = {}
-_c = 9
-for _b, _f in enumerate((64, 128, 256)):
-    for _conv, _bn, _cin in ((0, 1, _c), (3, 4, _f)):
-        EXPECTED_SHAPES[f"encoder.{_b}.{_conv}.weight"] = (_f, _cin, 3, 3)
-        EXPECTED_SHAPES[f"encoder.{_b}.{_conv}.bias"] = (_f,)
-        for _s in ("weight", "bias", "running_mean", "running_var"):
-            EXPECTED_SHAPES[f"encoder.{_b}.{_bn}.{_s}"] = (_f,)
-    _c = _f
 ATT_SPATIAL, ATT_CHANNEL, ATT_HYBRID, ATT_NONE = 0, 1, 2, 3   # include/leafgrasp.h LG_ATT_*
-for _p in ("attention.0", "spatial_attention.0"):
-    EXPECTED_SHAPES[f"{_p}.weight"] = (1, 256, 1, 1)
-    EXPECTED_SHAPES[f"{_p}.bias"] = (1,)
-for _p in ("attention", "channel_attention"):
-    EXPECTED_SHAPES[f"{_p}.1.weight"] = (16, 256, 1, 1)
-    EXPECTED_SHAPES[f"{_p}.1.bias"] = (16,)
-    EXPECTED_SHAPES[f"{_p}.3.weight"] = (256, 16, 1, 1)
-    EXPECTED_SHAPES[f"{_p}.3.bias"] = (256,)
-for _li, (_idx, _i, _o) in enumerate(((0, 256, 256), (4, 256, 128), (8, 128, 64), (12, 64, 1))):
-    EXPECTED_SHAPES[f"classifier.{_idx}.weight"] = (_o, _i)
-    EXPECTED_SHAPES[f"classifier.{_idx}.bias"] = (_o,)
-    if _idx != 12:
-        for _s in ("weight", "bias", "running_mean", "running_var"):
-            EXPECTED_SHAPES[f"classifier.{_idx + 1}.{_s}"] = (_o,)
+# encoder_filters of the reference's sweep (train_model_mlflow.py:177-182, mlflow_experiment_configs.py:86-112)
+SUPPORTED_FILTERS = ((32, 64, 128), (64, 128, 256), (64, 128, 256, 512), (128, 256, 512))
+
+
+def encoder_filters_of(state_dict):
+    """encoder_filters from the conv shapes of the state dict (block b: encoder.{b}.0.weight is [f_b, cin, 3, 3])."""
+    f = []
+    while f"encoder.{len(f)}.0.weight" in state_dict:
+        f.append(int(state_dict[f"encoder.{len(f)}.0.weight"].shape[0]))
+    return tuple(f)
+
+
+def expected_shapes(filters, in_channels=9):
+    shapes = {}
+    c = in_channels
+    for b, f in enumerate(filters):
+        for conv, bn, cin in ((0, 1, c), (3, 4, f)):
+            shapes[f"encoder.{b}.{conv}.weight"] = (f, cin, 3, 3)
+            shapes[f"encoder.{b}.{conv}.bias"] = (f,)
+            for s_ in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"encoder.{b}.{bn}.{s_}"] = (f,)
+        c = f
+    F = filters[-1]
+    for p in ("attention.0", "spatial_attention.0"):
+        shapes[f"{p}.weight"] = (1, F, 1, 1)
+        shapes[f"{p}.bias"] = (1,)
+    for p in ("attention", "channel_attention"):
+        shapes[f"{p}.1.weight"] = (F // 16, F, 1, 1)
+        shapes[f"{p}.1.bias"] = (F // 16,)
+        shapes[f"{p}.3.weight"] = (F, F // 16, 1, 1)
+        shapes[f"{p}.3.bias"] = (F,)
+    for idx, i, o in ((0, F, F), (4, F, F // 2), (8, F // 2, F // 4), (12, F // 4, 1)):
+        shapes[f"classifier.{idx}.weight"] = (o, i)
+        shapes[f"classifier.{idx}.bias"] = (o,)
+        if idx != 12:
+            for s_ in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"classifier.{idx + 1}.{s_}"] = (o,)
+    return shapes
+
+
+EXPECTED_SHAPES = expected_shapes((64, 128, 256))   # the node's default model
 
 
 def pack_state_dict(state_dict):
     """-> (LgCnnWeights, keepalive list).  Accepts torch tensors or numpy arrays; validates shapes."""
     keep = []
+    filters = encoder_filters_of(state_dict)
+    if filters not in SUPPORTED_FILTERS:
+        raise ValueError(f"GraspPointCNN encoder_filters {list(filters)} not supported (reference configurations: "
+                         f"{[list(f) for f in SUPPORTED_FILTERS]}, in_channels=9)")
+    shapes = expected_shapes(filters)
 
     def arr(key):
         if key not in state_dict:
@@ -47,15 +71,18 @@ def pack_state_dict(state_dict):
         if hasattr(v, "detach"):
             v = v.detach().cpu().numpy()
         a = np.ascontiguousarray(v, dtype=np.float32)
-        if tuple(a.shape) != EXPECTED_SHAPES[key]:
-            raise ValueError(f"'{key}' has shape {tuple(a.shape)}, expected {EXPECTED_SHAPES[key]} "
-                             "(only encoder_filters [64,128,256] with in_channels=9 is supported)")
+        if tuple(a.shape) != shapes[key]:
+            raise ValueError(f"'{key}' has shape {tuple(a.shape)}, expected {shapes[key]} "
+                             f"(encoder_filters {list(filters)}, in_channels=9)")
         keep.append(a)
         return a.ctypes.data_as(_FP)
 
     w = LgCnnWeights()
+    w.n_blocks = len(filters)
+    for i, f in enumerate(filters):
+        w.filters[i] = f
     li = 0
-    for b in range(3):
+    for b in range(len(filters)):
         for conv, bn in ((0, 1), (3, 4)):
             w.conv_w[li] = arr(f"encoder.{b}.{conv}.weight")
             w.conv_b[li] = arr(f"encoder.{b}.{conv}.bias")

@@ -1,5 +1,5 @@
-// GraspPointCNN (scripts/utils/ml_grasp_optimizer/model.py:5-128, eval mode, 'spatial' attention,
-// encoder_filters [64,128,256]) on gfx950: BN folded at load, 3x3 convs as implicit GEMM on
+// GraspPointCNN (scripts/utils/ml_grasp_optimizer/model.py:5-128, eval mode; the four attention types and the four
+// encoder_filters configurations of the reference's sweep) on gfx950: BN folded at load, 3x3 convs as implicit GEMM on
 // v_mfma_f32_32x32x2_f32 (exact fp32), fused bias+ReLU(+2x2 max-pool) epilogues.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -8,11 +8,18 @@
 
 #include "../../include/leafgrasp.h"
 
+struct RtLayer { int cin, cout, cinp, coutp, wi; bool pool; };   // real / padded channels, image width, 2x2 pool after it
+
 struct LgCnn {
     bool loaded = false;
-    float* wconv[6] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded
-    float* bconv[6] = {nullptr};
-    float* uwino[6] = {nullptr};  // Winograd F(2x2,3x3) weights [cin][cout][16] (layers 1..5)
+    int n_layers = 6;             // 2 conv layers per encoder block
+    RtLayer layers[8] = {};
+    bool standard = true;         // encoder [64,128,256]: the direct kernels / A-B switches exist for this one only
+    int F = 256, Fp = 256, npix = 16;   // final filters (real / padded), pixels of the last feature map
+    size_t act_per_patch = 64 * 32 * 32;  // floats of the largest activation per patch
+    float* wconv[8] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded (layer 0; all layers of the standard model)
+    float* bconv[8] = {nullptr};
+    float* uwino[8] = {nullptr};  // Winograd F(2x2,3x3) weights [cin][cout][16] (layers 1..)
     float* att_w = nullptr;       // [256] spatial attention (1x1 conv 256 -> 1)
     float att_b = 0.f;
     int att_type = 0;             // LG_ATT_*

@@ -26,8 +26,6 @@ __device__ float lg_zero_pad[4];  // zero-initialised source for padded / out-of
 namespace {
 
 struct LayerCfg { int cin, cinp, cout, wi; bool pool; };
-constexpr size_t kActPerPatch = 64 * 32 * 32;   // largest activation plane set per patch (conv1 output), floats
-constexpr size_t kZeroTail = 64 * 32 * 32 + 1024;  // zeroed floats behind each activation buffer (>= CIN*WI*WI of any layer)
 constexpr LayerCfg kLayers[6] = {
     {9, 10, 64, 32, false}, {64, 64, 64, 32, true},   {64, 64, 128, 16, false},
     {128, 128, 128, 16, true}, {128, 128, 256, 8, false}, {256, 256, 256, 8, true}};
@@ -640,11 +638,12 @@ __global__ __launch_bounds__(512, 1) void lg_wino_ws_kernel(const float* __restr
     }
 }
 
-// attention, global average pool, classifier 256->256->128->64->1 (BN folded).  model.py:30-60,63-84,108-128.
-//   spatial: x * sigmoid(conv1x1(x) 256->1)            channel: x * sigmoid(W2 relu(W1 gap(x) + b1) + b2)
-//   hybrid : x * spatial(x) * channel(x)                none   : x
-// One workgroup per patch, thread t = channel t holding its 16 pixels.
-__global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, int att_type,
+// attention, global average pool, classifier F -> F -> F/2 -> F/4 -> 1 (BN folded).  model.py:30-60,63-84,108-128.
+//   spatial: x * sigmoid(conv1x1(x) F->1)            channel: x * sigmoid(W2 relu(W1 gap(x) + b1) + b2), hidden F/16
+//   hybrid : x * spatial(x) * channel(x)              none   : x
+// One workgroup per patch; thread t holds channels t and t + 256 (F <= 512) with their npix (16 or 4) pixels.
+// h is [n][Cp][npix] (Cp = channel count padded to the conv kernels' 64-channel granule).
+__global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ h, int F, int Cp, int npix, int att_type,
                                                       const float* __restrict__ att_w, float att_b,
                                                       const float* __restrict__ ca_w1, const float* __restrict__ ca_b1,
                                                       const float* __restrict__ ca_w2, const float* __restrict__ ca_b2,
@@ -653,87 +652,96 @@ __global__ __launch_bounds__(256) void lg_head_kernel(const float* __restrict__ 
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, const float* __restrict__ w3,
                                                       const float* __restrict__ b3, float* __restrict__ logits) {
-    __shared__ float s_a[4][16];
-    __shared__ float s_f[256], s_g[256];
+    __shared__ float s_a[4][32];
+    __shared__ float s_f[512], s_g[512];
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float* hn = h + (size_t)n * 256 * 16;
-    float v[16];
+    const float* hn = h + (size_t)n * Cp * npix;
+    float v[2][16];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        float4 x = *reinterpret_cast<const float4*>(hn + t * 16 + 4 * q);
-        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    for (int i = 0; i < 2; i++) {
+        const int c = t + 256 * i;
+#pragma unroll
+        for (int p = 0; p < 16; p++) v[i][p] = (c < F && p < npix) ? hn[(size_t)c * npix + p] : 0.0f;
     }
     const bool spatial = att_type == LG_ATT_SPATIAL || att_type == LG_ATT_HYBRID;
     const bool channel = att_type == LG_ATT_CHANNEL || att_type == LG_ATT_HYBRID;
-    float f = 0.0f;   // mean over the pixels of x (* spatial attention)
+    const float inv_np = 1.0f / (float)npix;
+    // sum over all channels of a per-thread value, for up to 32 slots, through s_a (waves) -- result read by everyone
+    float f[2] = {0.0f, 0.0f};   // mean over the pixels of x (* spatial attention)
     if (spatial) {
-        const float aw = att_w[t];
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            float s = aw * v[p];
+        const float aw0 = t < F ? att_w[t] : 0.0f, aw1 = t + 256 < F ? att_w[t + 256] : 0.0f;
+        for (int p = 0; p < npix; p++) {
+            float s = aw0 * v[0][p] + aw1 * v[1][p];
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
             if (lane == 0) s_a[wave][p] = s;
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            float z = s_a[0][p] + s_a[1][p] + s_a[2][p] + s_a[3][p] + att_b;
-            float a = 1.0f / (1.0f + expf(-z));
-            f += v[p] * a;
+        for (int p = 0; p < npix; p++) {
+            const float z = s_a[0][p] + s_a[1][p] + s_a[2][p] + s_a[3][p] + att_b;
+            const float a = 1.0f / (1.0f + expf(-z));
+            f[0] += v[0][p] * a;
+            f[1] += v[1][p] * a;
         }
     } else {
-#pragma unroll
-        for (int p = 0; p < 16; p++) f += v[p];
+        for (int p = 0; p < npix; p++) { f[0] += v[0][p]; f[1] += v[1][p]; }
     }
-    f *= (1.0f / 16.0f);
-    if (channel) {   // squeeze-and-excitation on the un-attended x: gap -> 16 -> 256 -> sigmoid
-        float g = 0.0f;
-#pragma unroll
-        for (int p = 0; p < 16; p++) g += v[p];
-        g *= (1.0f / 16.0f);
+    f[0] *= inv_np; f[1] *= inv_np;
+    if (channel) {   // squeeze-and-excitation on the un-attended x: gap -> F/16 -> F -> sigmoid
+        const int hid = F / 16;
+        float g[2] = {0.0f, 0.0f};
+        for (int p = 0; p < npix; p++) { g[0] += v[0][p]; g[1] += v[1][p]; }
+        g[0] *= inv_np; g[1] *= inv_np;
         __syncthreads();   // s_a is reused
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            float s = ca_w1[j * 256 + t] * g;
+        for (int j = 0; j < hid; j++) {
+            float s = (t < F ? ca_w1[j * F + t] * g[0] : 0.0f) + (t + 256 < F ? ca_w1[j * F + t + 256] * g[1] : 0.0f);
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
             if (lane == 0) s_a[wave][j] = s;
         }
         __syncthreads();
-        float e = ca_b2[t];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float z = fmaxf(s_a[0][j] + s_a[1][j] + s_a[2][j] + s_a[3][j] + ca_b1[j], 0.0f);
-            e += ca_w2[t * 16 + j] * z;
+        for (int i = 0; i < 2; i++) {
+            const int c = t + 256 * i;
+            if (c < F) {
+                float e = ca_b2[c];
+                for (int j = 0; j < hid; j++) {
+                    const float z = fmaxf(s_a[0][j] + s_a[1][j] + s_a[2][j] + s_a[3][j] + ca_b1[j], 0.0f);
+                    e += ca_w2[c * hid + j] * z;
+                }
+                f[i] *= 1.0f / (1.0f + expf(-e));
+            }
         }
-        f *= 1.0f / (1.0f + expf(-e));
     }
-    s_f[t] = f;
+    s_f[t] = f[0]; s_f[t + 256] = f[1];
     __syncthreads();
-    {   // 256 -> 256
-        float s = b0[t];
-        for (int c = 0; c < 256; c++) s += w0[c * 256 + t] * s_f[c];
-        s_g[t] = fmaxf(s, 0.0f);
-    }
-    __syncthreads();
-    if (t < 128) {  // 256 -> 128
-        float s = b1[t];
-        for (int c = 0; c < 256; c++) s += w1[c * 128 + t] * s_g[c];
-        s_f[t] = fmaxf(s, 0.0f);
+    // classifier: weights transposed [in][out], BN folded
+    const int d1 = F, d2 = F / 2, d3 = F / 4;
+    for (int o = t; o < d1; o += 256) {
+        float s = b0[o];
+        for (int c = 0; c < F; c++) s += w0[c * d1 + o] * s_f[c];
+        s_g[o] = fmaxf(s, 0.0f);
     }
     __syncthreads();
-    if (t < 64) {  // 128 -> 64
-        float s = b2[t];
-        for (int c = 0; c < 128; c++) s += w2[c * 64 + t] * s_f[c];
-        s_g[t] = fmaxf(s, 0.0f);
+    for (int o = t; o < d2; o += 256) {
+        float s = b1[o];
+        for (int c = 0; c < d1; c++) s += w1[c * d2 + o] * s_g[c];
+        s_f[o] = fmaxf(s, 0.0f);
     }
     __syncthreads();
-    if (t < 64) {  // 64 -> 1
-        float s = w3[t] * s_g[t];
+    for (int o = t; o < d3; o += 256) {
+        float s = b2[o];
+        for (int c = 0; c < d2; c++) s += w2[c * d3 + o] * s_f[c];
+        s_g[o] = fmaxf(s, 0.0f);
+    }
+    __syncthreads();
+    {
+        float s = t < d3 ? w3[t] * s_g[t] : 0.0f;   // d3 <= 128
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (t == 0) logits[n] = s + b3[0];
+        if (lane == 0) s_a[wave][0] = s;
+        __syncthreads();
+        if (t == 0) logits[n] = s_a[0][0] + s_a[1][0] + s_a[2][0] + s_a[3][0] + b3[0];
     }
 }
 
@@ -749,6 +757,14 @@ void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t
                        s, in, c->wconv[L], c->bconv[L], out);
 }
 
+// layer 0 of any encoder (9 input channels -> 64 or 128 padded output channels at 32x32): direct implicit GEMM
+template <int COUT>
+void launch_conv0(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
+    const int grid = N * 4 * (COUT / 64);   // PP = 4: 8 rows per workgroup -> 4 bands
+    hipLaunchKernelGGL((lg_conv3x3_kernel<9, 10, COUT, 32, false, 10, 4, 1>), dim3(grid), dim3(256), 0, s, in, c->wconv[0],
+                       c->bconv[0], out);
+}
+
 template <int L, int KC>
 void launch_wino_ws(const float* in, const LgCnn* c, float* out, int N, hipStream_t s, int num_cu) {
     constexpr LayerCfg cfg = kLayers[L];
@@ -760,23 +776,42 @@ void launch_wino_ws(const float* in, const LgCnn* c, float* out, int N, hipStrea
                        c->uwino[L], c->bconv[L], out, N, ntb);
 }
 
-template <int L>
-void launch_wino(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
-    constexpr LayerCfg cfg = kLayers[L];
-    constexpr int TP = (cfg.wi / 2) * (cfg.wi / 2);
-    const int ntb = TP >= 32 ? N * (TP / 32) : (N + 32 / TP - 1) / (32 / TP);
-    const int grid = ntb * (cfg.cout / 64);
-    // the zeroed tail sits behind BOTH ping-pong buffers at the same element offset; `in` is one of them
-    const float* zero_tail = in + (size_t)c->capN * kActPerPatch;
-    hipLaunchKernelGGL((lg_wino_kernel<cfg.cin, cfg.cout, cfg.wi, cfg.pool>), dim3(grid), dim3(256), 0, s, in, c->uwino[L],
-                       c->bconv[L], out, zero_tail, N, ntb);
+// Winograd layer shapes of the four encoder configurations of the reference's sweep (train_model_mlflow.py:177-182;
+// 32-channel stages of 'lightweight' are zero-padded to the 64-channel granule): (cin, cout, width, pool)
+#define LG_WINO_SHAPES(X)                                                                                          \
+    X(64, 64, 32, true) X(64, 128, 16, false) X(128, 128, 16, true) X(128, 256, 8, false) X(256, 256, 8, true)     \
+    X(64, 64, 16, false) X(64, 64, 16, true) X(64, 128, 8, false) X(128, 128, 8, true)                             \
+    X(128, 128, 32, true) X(128, 256, 16, false) X(256, 256, 16, true) X(256, 512, 8, false) X(512, 512, 8, true)  \
+    X(256, 512, 4, false) X(512, 512, 4, true)
+
+bool wino_supported(int cin, int cout, int wi, bool pool) {
+#define X(CI, CO, W_, P) if (cin == CI && cout == CO && wi == W_ && pool == P) return true;
+    LG_WINO_SHAPES(X)
+#undef X
+    return false;
+}
+
+bool launch_wino_rt(int cin, int cout, int wi, bool pool, const float* in, const float* U, const float* bias, float* out,
+                    const float* zero_tail, int N, hipStream_t s) {
+    const int tp = (wi / 2) * (wi / 2);
+    const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
+    const int grid = ntb * (cout / 64);
+#define X(CI, CO, W_, P)                                                                                           \
+    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                        \
+        hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P>), dim3(grid), dim3(256), 0, s, in, U, bias, out, zero_tail, N, \
+                           ntb);                                                                                   \
+        return true;                                                                                               \
+    }
+    LG_WINO_SHAPES(X)
+#undef X
+    return false;
 }
 
 }  // namespace
 
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
-    for (int i = 0; i < 6; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); }
+    for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); }
     F(c->att_w); F(c->ca_w1); F(c->ca_b1); F(c->ca_w2); F(c->ca_b2);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
     F(c->act[0]); F(c->act[1]);
@@ -796,42 +831,75 @@ static int upload(float** dst, const std::vector<float>& v, std::string* err) {
 int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
     lg_cnn_free(c);
     const float eps = w->bn_eps > 0.f ? w->bn_eps : 1e-5f;
-    for (int L = 0; L < 6; L++) {
-        const LayerCfg cfg = kLayers[L];
+    // ---- layer plan: n_blocks x [conv(cin->f), conv(f->f), pool]; channels padded to the kernels' 64-channel granule
+    const int nb = w->n_blocks > 0 ? w->n_blocks : 3;
+    int filt[4] = {64, 128, 256, 0};
+    if (w->n_blocks > 0)
+        for (int b = 0; b < 4; b++) filt[b] = w->filters[b];
+    if (nb < 1 || nb > 4) { *err = "lg_cnn_load: 1..4 encoder blocks"; return LG_ERR_UNSUPPORTED; }
+    c->n_layers = 2 * nb;
+    int cin = 9, cinp = 10, wi = 32;
+    size_t per = 0;
+    for (int b = 0; b < nb; b++) {
+        const int f = filt[b], fp = (f + 63) / 64 * 64;
+        if (f < 16 || f > 512 || (f % 16) != 0) { *err = "lg_cnn_load: encoder filters must be multiples of 16 in [16, 512]"; return LG_ERR_UNSUPPORTED; }
+        c->layers[2 * b] = {cin, f, cinp, fp, wi, false};
+        c->layers[2 * b + 1] = {f, f, fp, fp, wi, true};
+        per = std::max(per, (size_t)fp * wi * wi);
+        cin = f; cinp = fp; wi /= 2;
+    }
+    c->F = filt[nb - 1]; c->Fp = (c->F + 63) / 64 * 64; c->npix = wi * wi;
+    c->act_per_patch = per;
+    c->standard = nb == 3 && filt[0] == 64 && filt[1] == 128 && filt[2] == 256;
+    if (c->layers[0].coutp != 64 && c->layers[0].coutp != 128) { *err = "lg_cnn_load: first stage wider than 128 channels"; return LG_ERR_UNSUPPORTED; }
+    for (int L = 1; L < c->n_layers; L++) {
+        const RtLayer& l = c->layers[L];
+        if (!wino_supported(l.cinp, l.coutp, l.wi, l.pool)) {
+            *err = "lg_cnn_load: encoder_filters outside the reference's configurations ([32,64,128], [64,128,256], "
+                   "[64,128,256,512], [128,256,512])";
+            return LG_ERR_UNSUPPORTED;
+        }
+    }
+    for (int L = 0; L < c->n_layers; L++) {
+        const RtLayer& l = c->layers[L];
         if (!w->conv_w[L] || !w->conv_b[L] || !w->bn_g[L] || !w->bn_b[L] || !w->bn_m[L] || !w->bn_v[L]) {
             *err = "lg_cnn_load: missing encoder tensor";
             return LG_ERR_INVALID;
         }
-        // fold eval-mode BatchNorm2d: y = (conv + b - mean) * g / sqrt(var + eps) + beta
-        std::vector<float> wp((size_t)9 * cfg.cinp * cfg.cout, 0.0f), bp(cfg.cout);
-        for (int co = 0; co < cfg.cout; co++) {
-            const double sc = (double)w->bn_g[L][co] / sqrt((double)w->bn_v[L][co] + (double)eps);
-            bp[co] = (float)(((double)w->conv_b[L][co] - (double)w->bn_m[L][co]) * sc + (double)w->bn_b[L][co]);
-            for (int ci = 0; ci < cfg.cin; ci++)
-                for (int tap = 0; tap < 9; tap++)
-                    wp[((size_t)tap * cfg.cinp + ci) * cfg.cout + co] =
-                        (float)((double)w->conv_w[L][((size_t)co * cfg.cin + ci) * 9 + tap] * sc);
+        // fold eval-mode BatchNorm2d: y = (conv + b - mean) * g / sqrt(var + eps) + beta; padded channels stay 0
+        std::vector<float> bp(l.coutp, 0.0f);
+        std::vector<double> scv(l.cout);
+        for (int co = 0; co < l.cout; co++) {
+            scv[co] = (double)w->bn_g[L][co] / sqrt((double)w->bn_v[L][co] + (double)eps);
+            bp[co] = (float)(((double)w->conv_b[L][co] - (double)w->bn_m[L][co]) * scv[co] + (double)w->bn_b[L][co]);
         }
-        int rc = upload(&c->wconv[L], wp, err);
+        int rc = upload(&c->bconv[L], bp, err);
         if (rc) return rc;
-        rc = upload(&c->bconv[L], bp, err);
-        if (rc) return rc;
+        if (L == 0 || c->standard) {   // direct implicit-GEMM weights [tap][cin_pad][cout] (layer 0; A/B path of the standard model)
+            std::vector<float> wp((size_t)9 * l.cinp * l.coutp, 0.0f);
+            for (int co = 0; co < l.cout; co++)
+                for (int ci = 0; ci < l.cin; ci++)
+                    for (int tap = 0; tap < 9; tap++)
+                        wp[((size_t)tap * l.cinp + ci) * l.coutp + co] =
+                            (float)((double)w->conv_w[L][((size_t)co * l.cin + ci) * 9 + tap] * scv[co]);
+            rc = upload(&c->wconv[L], wp, err);
+            if (rc) return rc;
+        }
         if (L >= 1) {
             // Winograd-domain weights U = G g G^T of the BN-folded kernel, layout [ci][co][4i+j], rounded once from double
-            std::vector<float> uw((size_t)cfg.cin * cfg.cout * 16);
-            for (int co = 0; co < cfg.cout; co++) {
-                const double sc = (double)w->bn_g[L][co] / sqrt((double)w->bn_v[L][co] + (double)eps);
-                for (int ci = 0; ci < cfg.cin; ci++) {
+            std::vector<float> uw((size_t)l.cinp * l.coutp * 16, 0.0f);
+            for (int co = 0; co < l.cout; co++) {
+                for (int ci = 0; ci < l.cin; ci++) {
                     double g[3][3], gg[4][3];
                     for (int tap = 0; tap < 9; tap++)
-                        g[tap / 3][tap % 3] = (double)w->conv_w[L][((size_t)co * cfg.cin + ci) * 9 + tap] * sc;
+                        g[tap / 3][tap % 3] = (double)w->conv_w[L][((size_t)co * l.cin + ci) * 9 + tap] * scv[co];
                     for (int j = 0; j < 3; j++) {
                         gg[0][j] = g[0][j];
                         gg[1][j] = 0.5 * (g[0][j] + g[1][j] + g[2][j]);
                         gg[2][j] = 0.5 * (g[0][j] - g[1][j] + g[2][j]);
                         gg[3][j] = g[2][j];
                     }
-                    float* u = &uw[((size_t)ci * cfg.cout + co) * 16];
+                    float* u = &uw[((size_t)ci * l.coutp + co) * 16];
                     for (int i = 0; i < 4; i++) {
                         u[4 * i + 0] = (float)gg[i][0];
                         u[4 * i + 1] = (float)(0.5 * (gg[i][0] + gg[i][1] + gg[i][2]));
@@ -844,24 +912,25 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
             if (rc) return rc;
         }
     }
+    const int F = c->F;
     c->att_type = w->attention_type;
     if (c->att_type < LG_ATT_SPATIAL || c->att_type > LG_ATT_NONE) { *err = "lg_cnn_load: unknown attention_type"; return LG_ERR_INVALID; }
     if (c->att_type == LG_ATT_SPATIAL || c->att_type == LG_ATT_HYBRID) {
         if (!w->att_w || !w->att_b) { *err = "lg_cnn_load: missing spatial attention tensor"; return LG_ERR_INVALID; }
-        std::vector<float> aw(w->att_w, w->att_w + 256);
-        int rc = upload(&c->att_w, aw, err);
+        int rc = upload(&c->att_w, std::vector<float>(w->att_w, w->att_w + F), err);
         if (rc) return rc;
         c->att_b = w->att_b[0];
     }
     if (c->att_type == LG_ATT_CHANNEL || c->att_type == LG_ATT_HYBRID) {
         if (!w->ca_w1 || !w->ca_b1 || !w->ca_w2 || !w->ca_b2) { *err = "lg_cnn_load: missing channel attention tensor"; return LG_ERR_INVALID; }
-        int rc = upload(&c->ca_w1, std::vector<float>(w->ca_w1, w->ca_w1 + 16 * 256), err);
-        if (!rc) rc = upload(&c->ca_b1, std::vector<float>(w->ca_b1, w->ca_b1 + 16), err);
-        if (!rc) rc = upload(&c->ca_w2, std::vector<float>(w->ca_w2, w->ca_w2 + 256 * 16), err);
-        if (!rc) rc = upload(&c->ca_b2, std::vector<float>(w->ca_b2, w->ca_b2 + 256), err);
+        const int hid = F / 16;
+        int rc = upload(&c->ca_w1, std::vector<float>(w->ca_w1, w->ca_w1 + (size_t)hid * F), err);
+        if (!rc) rc = upload(&c->ca_b1, std::vector<float>(w->ca_b1, w->ca_b1 + hid), err);
+        if (!rc) rc = upload(&c->ca_w2, std::vector<float>(w->ca_w2, w->ca_w2 + (size_t)F * hid), err);
+        if (!rc) rc = upload(&c->ca_b2, std::vector<float>(w->ca_b2, w->ca_b2 + F), err);
         if (rc) return rc;
     }
-    const int dims[5] = {256, 256, 128, 64, 1};
+    const int dims[5] = {F, F, F / 2, F / 4, 1};
     for (int L = 0; L < 4; L++) {
         const int fin = dims[L], fout = dims[L + 1];
         if (!w->fc_w[L] || !w->fc_b[L]) { *err = "lg_cnn_load: missing classifier tensor"; return LG_ERR_INVALID; }
@@ -890,13 +959,13 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
 
 static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err);
 
-// Slices of at most kMaxSlice patches share the activation workspace (the 32-bit staging offsets of lg_wino_kernel
-// reach 4 GiB; 8192 patches = 2 GiB of activations per buffer).
+// Slices share the activation workspace (the 32-bit staging offsets of lg_wino_kernel reach 4 GiB: at most ~2 GiB of
+// activations per buffer and slice, i.e. 8192 patches of the standard model).
 int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
     if (!c->loaded) { *err = "no model"; return LG_ERR_NO_MODEL; }
-    constexpr int kMaxSlice = 8192;
-    for (int off = 0; off < N; off += kMaxSlice) {
-        const int n = N - off < kMaxSlice ? N - off : kMaxSlice;
+    const int max_slice = (int)std::max<size_t>(64, ((size_t)1 << 31) / (c->act_per_patch * sizeof(float)));
+    for (int off = 0; off < N; off += max_slice) {
+        const int n = N - off < max_slice ? N - off : max_slice;
         int rc = lg_cnn_run_slice(c, patches + (size_t)off * 9 * 1024, n, logits + off, s, err);
         if (rc) return rc;
     }
@@ -904,51 +973,68 @@ int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t
 }
 
 static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
+    const size_t per = c->act_per_patch;
+    const size_t tail = per + 1024;   // zeroed floats behind each buffer: >= cin * width^2 of any layer
     if (N > c->capN) {
         hipStreamSynchronize(s);
         if (c->act[0]) hipFree(c->act[0]);
         if (c->act[1]) hipFree(c->act[1]);
         c->act[0] = c->act[1] = nullptr;
-        const size_t per = kActPerPatch;
-        if (hipMalloc((void**)&c->act[0], ((size_t)N * per + kZeroTail) * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&c->act[1], ((size_t)N * per + kZeroTail) * sizeof(float)) != hipSuccess) {
+        if (hipMalloc((void**)&c->act[0], ((size_t)N * per + tail) * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&c->act[1], ((size_t)N * per + tail) * sizeof(float)) != hipSuccess) {
             *err = "lg_cnn_forward: activation workspace allocation failed";
             c->capN = 0;
             return LG_ERR_NOMEM;
         }
-        hipMemsetAsync(c->act[0] + (size_t)N * per, 0, kZeroTail * sizeof(float), s);
-        hipMemsetAsync(c->act[1] + (size_t)N * per, 0, kZeroTail * sizeof(float), s);
+        hipMemsetAsync(c->act[0] + (size_t)N * per, 0, tail * sizeof(float), s);
+        hipMemsetAsync(c->act[1] + (size_t)N * per, 0, tail * sizeof(float), s);
         c->capN = N;
     }
     float *A = c->act[0], *B = c->act[1];
-    //            L  KC PP CP
-    launch_conv<0, 10, 4, 1>(patches, c, A, N, s);   // 9 -> 64, 32x32
-    // Winograd F(2x2,3x3) for layers 1..5 (2.25x fewer MFMA flops); LG_CNN_DIRECT=1 selects the direct implicit GEMM
-    // for all layers, LG_CNN_WINO_MASK=<bits> a per-layer choice (bit L = layer L on Winograd) -- A/B and test switches,
-    // read per call.
-    int wmask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
-    if (const char* e = getenv("LG_CNN_WINO_MASK")) wmask = atoi(e) & 0x3e;
-    // default: the lock-step kernel (4.01 ms per 2560 patches); LG_CNN_WS_KC=8 selects the producer/consumer form (4.45 ms)
-    const int ws_kc = getenv("LG_CNN_WS_KC") ? atoi(getenv("LG_CNN_WS_KC")) : 0;  // read per call (tests)
-    static const int num_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (const char* e = getenv("LG_CNN_WS_GRID")) n = atoi(e);
-        return n > 0 ? n : 256;
-    }();
-#define LG_WINO(L, A_, B_)                                               \
-    do {                                                                 \
-        if (ws_kc == 8) launch_wino_ws<L, 8>(A_, c, B_, N, s, num_cu); \
-        else launch_wino<L>(A_, c, B_, N, s);                            \
+    const size_t tail_off = (size_t)c->capN * per;   // the zeroed tail sits behind BOTH buffers at the same offset
+    if (c->layers[0].coutp == 64) launch_conv0<64>(patches, c, A, N, s);
+    else launch_conv0<128>(patches, c, A, N, s);
+    float* cur = A;
+    float* nxt = B;
+    if (c->standard) {
+        // Winograd F(2x2,3x3) for layers 1..5 (2.25x fewer MFMA flops); LG_CNN_DIRECT=1 selects the direct implicit GEMM
+        // for all layers, LG_CNN_WINO_MASK=<bits> a per-layer choice (bit L = layer L on Winograd), LG_CNN_WS_KC=8 the
+        // producer/consumer form (4.45 vs 4.01 ms per 2560 patches) -- A/B and test switches, read per call.
+        int wmask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
+        if (const char* e = getenv("LG_CNN_WINO_MASK")) wmask = atoi(e) & 0x3e;
+        const int ws_kc = getenv("LG_CNN_WS_KC") ? atoi(getenv("LG_CNN_WS_KC")) : 0;
+        static const int num_cu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (const char* e = getenv("LG_CNN_WS_GRID")) n = atoi(e);
+            return n > 0 ? n : 256;
+        }();
+#define LG_LAYER(L, KC, PP, CP)                                                                                     \
+    do {                                                                                                            \
+        const RtLayer& l = c->layers[L];                                                                            \
+        if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, nxt, N, s);                                     \
+        else if (ws_kc == 8) launch_wino_ws<L, 8>(cur, c, nxt, N, s, num_cu);                                       \
+        else launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, cur, c->uwino[L], c->bconv[L], nxt, cur + tail_off, N, s); \
+        std::swap(cur, nxt);                                                                                        \
     } while (0)
-    if (wmask & 2) LG_WINO(1, A, B); else launch_conv<1, 8, 4, 1>(A, c, B, N, s);   // 64 -> 64, pool -> 16x16
-    if (wmask & 4) LG_WINO(2, B, A); else launch_conv<2, 8, 4, 1>(B, c, A, N, s);   // 64 -> 128, 16x16
-    if (wmask & 8) LG_WINO(3, A, B); else launch_conv<3, 8, 4, 1>(A, c, B, N, s);   // 128 -> 128, pool -> 8x8
-    if (wmask & 16) LG_WINO(4, B, A); else launch_conv<4, 4, 1, 4>(B, c, A, N, s);  // 128 -> 256, 8x8
-    if (wmask & 32) LG_WINO(5, A, B); else launch_conv<5, 4, 1, 4>(A, c, B, N, s);  // 256 -> 256, pool -> 4x4
-#undef LG_WINO
-    hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, B, c->att_type, c->att_w, c->att_b, c->ca_w1, c->ca_b1,
-                       c->ca_w2, c->ca_b2, c->fcw[0], c->fcb[0], c->fcw[1],
-                       c->fcb[1], c->fcw[2], c->fcb[2], c->fcw[3], c->fcb[3], logits);
+        LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
+        LG_LAYER(2, 8, 4, 1);   // 64 -> 128, 16x16
+        LG_LAYER(3, 8, 4, 1);   // 128 -> 128, pool -> 8x8
+        LG_LAYER(4, 4, 1, 4);   // 128 -> 256, 8x8
+        LG_LAYER(5, 4, 1, 4);   // 256 -> 256, pool -> 4x4
+#undef LG_LAYER
+    } else {
+        for (int L = 1; L < c->n_layers; L++) {
+            const RtLayer& l = c->layers[L];
+            if (!launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, cur, c->uwino[L], c->bconv[L], nxt, cur + tail_off, N, s)) {
+                *err = "lg_cnn_forward: unsupported layer shape";
+                return LG_ERR_UNSUPPORTED;
+            }
+            std::swap(cur, nxt);
+        }
+    }
+    hipLaunchKernelGGL(lg_head_kernel, dim3(N), dim3(256), 0, s, cur, c->F, c->Fp, c->npix, c->att_type, c->att_w, c->att_b,
+                       c->ca_w1, c->ca_b1, c->ca_w2, c->ca_b2, c->fcw[0], c->fcb[0], c->fcw[1], c->fcb[1], c->fcw[2],
+                       c->fcb[2], c->fcw[3], c->fcb[3], logits);
     return LG_OK;
 }

@@ -546,13 +546,13 @@ def _hash_unit(idx, salt):
     return x.astype(np.float64) / 4294967296.0 * 2.0 - 1.0
 
 
-def cnn_closed_form_params(seed=0, in_channels=9, attention_type="spatial"):
+def cnn_closed_form_params(seed=0, in_channels=9, attention_type="spatial", filters=CNN_FILTERS):
     """Deterministic closed-form fill (no trained best_model.pth exists in the reference tree,
     SURVEY 8d): integer-hash uniform weights with kaiming-uniform scale, non-trivial BN
     gamma/beta/mean/var so BN folding is exercised.  Logits vary with the input (unlike a
     smooth sin fill, which averages out under global pooling)."""
     params = {}
-    for i, (name, shp) in enumerate(cnn_param_shapes(in_channels, attention_type=attention_type).items()):
+    for i, (name, shp) in enumerate(cnn_param_shapes(in_channels, filters, attention_type).items()):
         n = int(np.prod(shp))
         base = _hash_unit(np.arange(n), 7919 * (i + 1) + 104729 * seed)
         if name.endswith("running_var"):
@@ -593,8 +593,11 @@ def cnn_forward(params, x, dtype=None):
     dt = dtype or torch.float32
     p = {k: torch.as_tensor(v).to(dt) for k, v in params.items()}
     h = torch.as_tensor(x).to(dt)
+    n_blocks = 0
+    while f"encoder.{n_blocks}.0.weight" in p:
+        n_blocks += 1
     with torch.no_grad():
-        for b in range(3):
+        for b in range(n_blocks):
             for conv, bn in ((0, 1), (3, 4)):
                 h = F.conv2d(h, p[f"encoder.{b}.{conv}.weight"], p[f"encoder.{b}.{conv}.bias"], padding=1)
                 h = F.batch_norm(h, p[f"encoder.{b}.{bn}.running_mean"], p[f"encoder.{b}.{bn}.running_var"],

@@ -296,6 +296,23 @@ def test_cnn_attention_variants_vs_reference(sel):
         got = sel.cnn_forward(x).cpu().numpy()
         np.testing.assert_allclose(got, g[f"logits_{att}"], rtol=1e-4, atol=1e-5, err_msg=att)
         np.testing.assert_allclose(got, g[f"logits_f64_{att}"], rtol=1e-4, atol=1e-5, err_msg=att)
+    # encoder_filters variants (32-channel stages zero-padded to 64; a fourth 4x4 stage; 512-channel head)
+    for name, filt, att in (("lightweight", (32, 64, 128), "spatial"), ("deep", (64, 128, 256, 512), "hybrid"),
+                            ("wide", (128, 256, 512), "none")):
+        params = O.cnn_closed_form_params(seed=2, attention_type=att, filters=filt)
+        sel.set_cnn_state_dict(params)
+        got = sel.cnn_forward(x).cpu().numpy()
+        np.testing.assert_allclose(got, g[f"logits_{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(got, g[f"logits_f64_{name}"], rtol=1e-4, atol=1e-5, err_msg=name)
+        for n in (1, 3, 9):   # 4x4 / 8x8 stages put 8 / 2 patches into one workgroup: ragged counts
+            np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), got[:n], err_msg=f"{name} n={n}")
+    with pytest.raises(Exception):
+        sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=2, filters=(48, 96, 192)))
+    # back to the default model: the per-handle plan is rebuilt
+    sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
+    x20 = torch.from_numpy(O.synthetic_patches(20, seed=5)).cuda()
+    np.testing.assert_allclose(sel.cnn_forward(x20).cpu().numpy(), O.cnn_forward(O.cnn_closed_form_params(seed=0), x20.cpu().numpy()),
+                               rtol=1e-4, atol=1e-5)
     sel.clear_cnn()
 
 

@@ -160,3 +160,8 @@ def test_cnn_attention_variants_match_reference():
     for att in ("channel", "hybrid", "none"):
         p = O.cnn_closed_form_params(seed=1, attention_type=att)
         np.testing.assert_allclose(O.cnn_forward(p, x), g[f"logits_{att}"], rtol=1e-5, atol=1e-6, err_msg=att)
+    # encoder_filters of the sweep (train_model_mlflow.py:177-182), paired like scripts/demo_mlflow_setup.py:44-49
+    for name, filt, att in (("lightweight", (32, 64, 128), "spatial"), ("deep", (64, 128, 256, 512), "hybrid"),
+                            ("wide", (128, 256, 512), "none")):
+        p = O.cnn_closed_form_params(seed=2, attention_type=att, filters=filt)
+        np.testing.assert_allclose(O.cnn_forward(p, x), g[f"logits_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
