@@ -173,6 +173,12 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
 int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H, int W,
                   float cx, float cy, float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves,
                   int32_t* extrema, void* stream);
+/* The same for B frames per call: labels / depth [B][H][W] DEVICE; stats [B][max_leaves], n_leaves [B], extrema [B][4],
+   status [B] HOST (per-frame lg_status: a frame with more than 64 labels fails alone).  Every pass carries the frame
+   in its grid; there is no host round trip between the passes. */
+int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
+                        float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
+                        void* stream);
 
 /* GraspPointSelector.estimate_leaf_orientation (:718-752) for one frame: mask [H][W] u8 DEVICE.
    out (HOST, 5 floats): angle (rad, direction of the longer side of the min-area rectangle of the largest

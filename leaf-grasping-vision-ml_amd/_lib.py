@@ -68,6 +68,9 @@ SYMBOLS = {
                                   C.POINTER(_VP * LG_NUM_MAPS), _VP, C.POINTER(LgGraspResult), _VP]),
     "lg_leaf_stats": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(LgLeafStat), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32), _VP]),
+    "lg_leaf_stats_batch": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                      C.POINTER(LgLeafStat), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int), _VP]),
     "lg_leaf_orientation": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _FP, C.POINTER(C.c_int), _VP]),
     "lg_profile_enable": (C.c_int, [_VP, C.c_int]),
     "lg_profile_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

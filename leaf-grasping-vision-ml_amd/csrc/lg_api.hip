@@ -691,6 +691,21 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
     return LG_OK;
 }
 
+int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
+                        float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
+                        void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!labels || !depth || !stats || !n_leaves || !extrema || !status || B < 1 || H < 1 || W < 1 || max_leaves < 1)
+        return fail(h, LG_ERR_INVALID, "lg_leaf_stats_batch: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    std::string err;
+    ProfScope ps(h, "leaf", s);
+    int rc = lg_leaf_run_batch(h->leaf, labels, depth, B, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, status, s, &err);
+    if (rc) return fail(h, rc, err.c_str());
+    return LG_OK;
+}
+
 int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
     if (!h || !w) return LG_ERR_INVALID;
     LG_HIP(h, hipSetDevice(h->device));

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #define LGL_MAXL 64          // labels per frame supported by the LDS histograms
@@ -33,6 +34,8 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __global__ __launch_bounds__(256) void k_presence(const int16_t* __restrict__ lab, long long n,
                                                   unsigned long long* __restrict__ pres) {
     __shared__ unsigned long long s_p[512];
+    lab += (size_t)blockIdx.y * n;     // frame = blockIdx.y
+    pres += (size_t)blockIdx.y * 512;
     for (int i = threadIdx.x; i < 512; i += 256) s_p[i] = 0;
     __syncthreads();
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -53,13 +56,15 @@ __global__ __launch_bounds__(256) void k_presence(const int16_t* __restrict__ la
 
 // prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1))
 __global__ void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    pres += (size_t)blockIdx.x * 512;  // one workgroup per frame
+    pre += (size_t)blockIdx.x * 512;
+    if (threadIdx.x == 0) {
         int acc = 0;
         for (int w = 0; w < 512; w++) {
             pre[w] = acc;
             acc += __popcll(pres[w]);
         }
-        *nlab = acc;
+        nlab[blockIdx.x] = acc;
     }
 }
 
@@ -83,6 +88,10 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                                                     LeafAcc* __restrict__ acc, unsigned long long* __restrict__ first_leaf) {
     __shared__ LeafAcc s_acc[LGL_MAXL];
     __shared__ unsigned long long s_first;
+    {
+        const size_t fr = blockIdx.y;
+        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; acc += fr * LGL_MAXL; first_leaf += fr;
+    }
     for (int i = threadIdx.x; i < LGL_MAXL; i += 256) {
         s_acc[i].area = 0; s_acc[i].sum_x = 0; s_acc[i].sum_y = 0;
         s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0;
@@ -148,11 +157,28 @@ struct SelState {       // per slot
     uint32_t key;       // selected key (after the last pass)
 };
 
+// median ranks from the per-slot areas (lower median index), one workgroup per frame
+__global__ void k_seed(const LeafAcc* __restrict__ acc, SelState* __restrict__ st) {
+    const size_t fr = blockIdx.x;
+    const int i = threadIdx.x;
+    if (i >= LGL_MAXL) return;
+    const unsigned long long a = acc[fr * LGL_MAXL + i].area;
+    SelState z;
+    z.prefix = 0; z.key = 0; z.n_le = 0;
+    z.rank = a ? (uint32_t)((a - 1) / 2) : 0;
+    st[fr * LGL_MAXL + i] = z;
+}
+
 // histogram of digit `pass` (3 = most significant byte) among elements whose higher bytes match the prefix
 __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, const float* __restrict__ depth, int H, int W,
                                               const unsigned long long* __restrict__ pres, const int* __restrict__ pre,
                                               const SelState* __restrict__ st, int pass, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_h[LGL_MAXL * 256];
+    {
+        const size_t fr = blockIdx.y;
+        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; st += fr * LGL_MAXL;
+        hist += fr * LGL_MAXL * 256;
+    }
     for (int i = threadIdx.x; i < LGL_MAXL * 256; i += 256) s_h[i] = 0;
     __syncthreads();
     const int shift = 8 * pass;
@@ -196,6 +222,8 @@ __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, c
 __global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, int pass, int nslots_max) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots_max) return;
+    st += (size_t)blockIdx.y * LGL_MAXL;
+    hist += (size_t)blockIdx.y * LGL_MAXL * 256;
     uint32_t* h = hist + s * 256;
     uint32_t rank = st[s].rank, accum = 0;
     int bin = 255;
@@ -220,6 +248,10 @@ __global__ __launch_bounds__(256) void k_successor(const int16_t* __restrict__ l
                                                    const int* __restrict__ pre, const SelState* __restrict__ st,
                                                    uint32_t* __restrict__ succ) {
     __shared__ uint32_t s_m[LGL_MAXL];
+    {
+        const size_t fr = blockIdx.y;
+        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; st += fr * LGL_MAXL; succ += fr * LGL_MAXL;
+    }
     for (int i = threadIdx.x; i < LGL_MAXL; i += 256) s_m[i] = 0xFFFFFFFFu;
     __syncthreads();
     const long long n = (long long)H * W;
@@ -242,6 +274,8 @@ __global__ __launch_bounds__(256) void k_successor(const int16_t* __restrict__ l
 __global__ __launch_bounds__(256) void k_coldist(const int16_t* __restrict__ lab, int H, int W, uint16_t* __restrict__ g) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
+    lab += (size_t)blockIdx.y * H * W;
+    g += (size_t)blockIdx.y * H * W;
     int d = LGL_GINF;
 #pragma unroll 8
     for (int y = 0; y < H; y++) {
@@ -264,7 +298,11 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
                                                unsigned long long* __restrict__ best) {
     __shared__ int s_g2[WP2];
     __shared__ int s_opt[WP2 + 1];
+    __shared__ int s_big[WP2 / 64 + 2];
+    __shared__ int s_nbig;
     const int y = blockIdx.x, lane = threadIdx.x;
+    g += (size_t)blockIdx.y * H * W;
+    best += (size_t)blockIdx.y * H;     // per-row results: H x B same-address atomics would serialise at one L2 channel
     for (int x = lane; x < WP2; x += 64) {
         int v = (x < W) ? (int)g[(size_t)y * W + x] : LGL_GINF;
         s_g2[x] = v * v;
@@ -275,38 +313,24 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
     // level l solves positions p = (2i+1) * WP2 / 2^(l+1); neighbours p -/+ half are solved (or the borders)
     for (int half = WP2 / 2; half >= 1; half >>= 1) {
         const int nsub = WP2 / (2 * half);
-        if (nsub < 64) {
-            const int lanes_per = 64 / nsub;        // lanes cooperating on one position
-            const int sub = lane / lanes_per, li = lane % lanes_per;
-            const int p = (2 * sub + 1) * half;
-            const int lo = (p - half > 0) ? s_opt[p - half] : 0;
-            const int hi = (p + half < WP2) ? s_opt[p + half] : W - 1;
-            int bc = INT_MAX, bx = lo;
-            if (p < W)
-                for (int xp = lo + li; xp <= hi; xp += lanes_per) {
-                    int c = cost(p, xp);
-                    if (c < bc) { bc = c; bx = xp; }
-                }
-            for (int o = 1; o < lanes_per; o <<= 1) {   // leftmost arg-min across the cooperating lanes
-                int oc = __shfl_xor(bc, o, 64), ox = __shfl_xor(bx, o, 64);
-                if (oc < bc || (oc == bc && ox < bx)) { bc = oc; bx = ox; }
-            }
+        {
+            // One position per lane and round.  The brackets of a level add up to <= W + nsub columns, but where the
+            // arg-min jumps between two leaves a single bracket spans the whole gap (hundreds of columns) at EVERY level:
+            // left to its lane it serialises the wave (measured 300 us per row).  Brackets wider than 64 columns are
+            // queued and searched afterwards by all 64 lanes together.
+            if (lane == 0) s_nbig = 0;
             __syncthreads();
-            if (li == 0) {
-                s_opt[p] = (p < W) ? bx : W - 1;
-                if (p < W && bc > 0) {
-                    unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W + p));
-                    mykey = key > mykey ? key : mykey;
-                }
-            }
-            __syncthreads();
-        } else {
             for (int sub = lane; sub < nsub; sub += 64) {
                 const int p = (2 * sub + 1) * half;
                 int res = W - 1;
                 if (p < W) {
                     const int lo = (p - half > 0) ? s_opt[p - half] : 0;
                     const int hi = (p + half < WP2) ? s_opt[p + half] : W - 1;
+                    if (hi - lo > 64) {
+                        const int q = atomicAdd(&s_nbig, 1);
+                        s_big[q] = p;          // at most W / 64 such brackets per level
+                        continue;              // s_opt[p] is written by the cooperative pass (nobody reads it before)
+                    }
                     int bc = INT_MAX, bx = lo;
                     for (int xp = lo; xp <= hi; xp++) {
                         int c = cost(p, xp);
@@ -319,6 +343,30 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
                     }
                 }
                 s_opt[p] = res;
+            }
+            __syncthreads();
+            const int nbig = s_nbig;
+            for (int q = 0; q < nbig; q++) {
+                const int p = s_big[q];
+                const int lo = (p - half > 0) ? s_opt[p - half] : 0;
+                const int hi = (p + half < WP2) ? s_opt[p + half] : W - 1;
+                int bc = INT_MAX, bx = lo;
+                for (int xp = lo + lane; xp <= hi; xp += 64) {
+                    int c = cost(p, xp);
+                    if (c < bc) { bc = c; bx = xp; }
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {   // leftmost arg-min across the wave
+                    int oc = __shfl_xor(bc, o, 64), ox = __shfl_xor(bx, o, 64);
+                    if (oc < bc || (oc == bc && ox < bx)) { bc = oc; bx = ox; }
+                }
+                if (lane == 0) {
+                    s_opt[p] = bx;
+                    if (bc > 0) {
+                        unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W + p));
+                        mykey = key > mykey ? key : mykey;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -338,12 +386,32 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
         unsigned long long w = __shfl_xor(mykey, o, 64);
         mykey = w > mykey ? w : mykey;
     }
-    if (lane == 0 && mykey) atomicMax(best, mykey);
+    if (lane == 0) best[y] = mykey;
+}
+
+// max over the rows of a frame (one workgroup per frame)
+__global__ __launch_bounds__(256) void k_rowbest(const unsigned long long* __restrict__ rowbest, int H,
+                                                 unsigned long long* __restrict__ best) {
+    __shared__ unsigned long long s_b[4];
+    const unsigned long long* rb = rowbest + (size_t)blockIdx.x * H;
+    unsigned long long m = 0;
+    for (int y = threadIdx.x; y < H; y += 256) m = rb[y] > m ? rb[y] : m;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long w = __shfl_xor(m, o, 64);
+        m = w > m ? w : m;
+    }
+    if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) m = s_b[i] > m ? s_b[i] : m;
+        best[blockIdx.x] = m;
+    }
 }
 
 }  // namespace
 
-struct LgLeafWs {
+struct LgLeafWs {   // every array holds capB frames back to back
     unsigned long long* pres;  // 512
     int* pre;                  // 512
     int* nlab;                 // 1
@@ -354,131 +422,163 @@ struct LgLeafWs {
     uint32_t* succ;            // MAXL
     unsigned long long* best;  // 1
     uint16_t* g;               // H*W
-    size_t g_cap;
+    unsigned long long* rowbest;  // H
+    size_t g_cap, rb_cap;
+    int capB;
 };
 
 void lg_leaf_free(LgLeafWs*& w) {
     if (!w) return;
-    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g};
+    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g, w->rowbest};
     for (void* p : ps)
         if (p) hipFree(p);
     delete w;
     w = nullptr;
 }
 
-static int leaf_ws(LgLeafWs*& w, int H, int W) {
+static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
+    if (w && B > w->capB) lg_leaf_free(w);
     if (!w) {
         w = new LgLeafWs();
         memset(w, 0, sizeof(*w));
-        if (hipMalloc((void**)&w->pres, 512 * 8) || hipMalloc((void**)&w->pre, 512 * 4) || hipMalloc((void**)&w->nlab, 4) ||
-            hipMalloc((void**)&w->acc, sizeof(LeafAcc) * LGL_MAXL) || hipMalloc((void**)&w->first_leaf, 8) ||
-            hipMalloc((void**)&w->st, sizeof(SelState) * LGL_MAXL) || hipMalloc((void**)&w->hist, 4 * LGL_MAXL * 256) ||
-            hipMalloc((void**)&w->succ, 4 * LGL_MAXL) || hipMalloc((void**)&w->best, 8))
+        const size_t nb = (size_t)B;
+        if (hipMalloc((void**)&w->pres, nb * 512 * 8) || hipMalloc((void**)&w->pre, nb * 512 * 4) ||
+            hipMalloc((void**)&w->nlab, nb * 4) || hipMalloc((void**)&w->acc, nb * sizeof(LeafAcc) * LGL_MAXL) ||
+            hipMalloc((void**)&w->first_leaf, nb * 8) || hipMalloc((void**)&w->st, nb * sizeof(SelState) * LGL_MAXL) ||
+            hipMalloc((void**)&w->hist, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->succ, nb * 4 * LGL_MAXL) ||
+            hipMalloc((void**)&w->best, nb * 8))
             return LG_ERR_NOMEM;
+        w->capB = B;
     }
-    size_t need = (size_t)H * W;
+    size_t need = (size_t)w->capB * H * W;
     if (need > w->g_cap) {
         if (w->g) hipFree(w->g);
         w->g = nullptr;
+        w->g_cap = 0;
         if (hipMalloc((void**)&w->g, need * 2)) return LG_ERR_NOMEM;
         w->g_cap = need;
+    }
+    const size_t need_rb = (size_t)w->capB * H;
+    if (need_rb > w->rb_cap) {
+        if (w->rowbest) hipFree(w->rowbest);
+        w->rowbest = nullptr;
+        w->rb_cap = 0;
+        if (hipMalloc((void**)&w->rowbest, need_rb * 8)) return LG_ERR_NOMEM;
+        w->rb_cap = need_rb;
     }
     return LG_OK;
 }
 
-int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
-                lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, std::string* err) {
-    int rc = leaf_ws(w, H, W);
+// B frames per call: every kernel carries the frame in blockIdx.y (blockIdx.x for the one-workgroup-per-frame steps), no
+// host round trip between the passes (the median ranks are seeded on the device), one copy-back at the end.
+int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
+                      float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
+                      hipStream_t s, std::string* err) {
+    int rc = leaf_ws(w, B, H, W);
     if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
+    if (W > 4096) { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
     const long long n = (long long)H * W;
-    const int grid = 1024;
-    hipMemsetAsync(w->pres, 0, 512 * 8, s);
-    hipMemsetAsync(w->acc, 0, sizeof(LeafAcc) * LGL_MAXL, s);
-    hipMemsetAsync(w->first_leaf, 0xFF, 8, s);
-    hipMemsetAsync(w->hist, 0, 4 * LGL_MAXL * 256, s);
-    hipMemsetAsync(w->succ, 0xFF, 4 * LGL_MAXL, s);
-    hipMemsetAsync(w->best, 0, 8, s);
-    hipLaunchKernelGGL(k_presence, dim3(grid), dim3(256), 0, s, labels, n, w->pres);
-    hipLaunchKernelGGL(k_prefix, dim3(1), dim3(64), 0, s, w->pres, w->pre, w->nlab);
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc,
+    const size_t nb = (size_t)B;
+    // streaming passes: grid-stride workgroups per frame; fewer per frame for large batches (every workgroup ends with a
+    // flush of its LDS accumulators / 64 KB histogram into global atomics)
+    const int gx = std::max(16, std::min(256, 2048 / B));   // (one per CU for a single frame: every workgroup of a frame ends
+                                                             //  with atomics on that frame's few accumulator addresses)
+    const dim3 grid(gx, B);
+    hipMemsetAsync(w->pres, 0, nb * 512 * 8, s);
+    hipMemsetAsync(w->acc, 0, nb * sizeof(LeafAcc) * LGL_MAXL, s);
+    hipMemsetAsync(w->first_leaf, 0xFF, nb * 8, s);
+    hipMemsetAsync(w->hist, 0, nb * 4 * LGL_MAXL * 256, s);
+    hipMemsetAsync(w->succ, 0xFF, nb * 4 * LGL_MAXL, s);
+    hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, s, labels, n, w->pres);
+    hipLaunchKernelGGL(k_prefix, dim3(B), dim3(64), 0, s, w->pres, w->pre, w->nlab);
+    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc,
                        w->first_leaf);
     // clutter extrema (independent of the statistics)
-    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256), dim3(256), 0, s, labels, H, W, w->g);
-    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
-    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
-    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
-    else if (W <= 4096) hipLaunchKernelGGL(k_rowedt<4096>, dim3(H), dim3(64), 0, s, w->g, H, W, w->best);
-    else { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
-    // need the areas on the host to seed the median ranks
-    int nlab = 0;
-    std::vector<LeafAcc> acc(LGL_MAXL);
-    std::vector<unsigned long long> pres(512);
-    if (hipMemcpyAsync(&nlab, w->nlab, 4, hipMemcpyDeviceToHost, s) || hipMemcpyAsync(acc.data(), w->acc, sizeof(LeafAcc) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(pres.data(), w->pres, 512 * 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s)) {
-        *err = "lg_leaf_stats: device copy failed";
-        return LG_ERR_HIP;
+    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s, labels, H, W, w->g);
+    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else hipLaunchKernelGGL(k_rowedt<4096>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    hipLaunchKernelGGL(k_rowbest, dim3(B), dim3(256), 0, s, w->rowbest, H, w->best);
+    // exact medians: ranks from the areas, 4 radix passes, successor for even counts
+    hipLaunchKernelGGL(k_seed, dim3(B), dim3(LGL_MAXL), 0, s, w->acc, w->st);
+    for (int pass = 3; pass >= 0; pass--) {
+        hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, pass, w->hist);
+        hipLaunchKernelGGL(k_select, dim3(1, B), dim3(LGL_MAXL), 0, s, w->st, w->hist, pass, LGL_MAXL);
     }
-    if (nlab > LGL_MAXL) { *err = "lg_leaf_stats: more than 64 distinct leaf labels in one frame"; return LG_ERR_UNSUPPORTED; }
-    if (nlab > max_leaves) { *err = "lg_leaf_stats: stats capacity too small"; return LG_ERR_INVALID; }
-    std::vector<SelState> st(LGL_MAXL);
-    for (int i = 0; i < LGL_MAXL; i++) {
-        st[i].prefix = 0; st[i].key = 0; st[i].n_le = 0;
-        st[i].rank = (i < nlab && acc[i].area) ? (uint32_t)((acc[i].area - 1) / 2) : 0;  // lower median index
-    }
-    hipMemcpyAsync(w->st, st.data(), sizeof(SelState) * LGL_MAXL, hipMemcpyHostToDevice, s);
-    if (nlab > 0) {
-        for (int pass = 3; pass >= 0; pass--) {
-            hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, pass, w->hist);
-            hipLaunchKernelGGL(k_select, dim3(1), dim3(LGL_MAXL), 0, s, w->st, w->hist, pass, LGL_MAXL);
-        }
-        hipLaunchKernelGGL(k_successor, dim3(grid), dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, w->succ);
-    }
-    std::vector<uint32_t> succ(LGL_MAXL);
-    unsigned long long first_leaf = 0, best = 0;
-    if (hipMemcpyAsync(st.data(), w->st, sizeof(SelState) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(succ.data(), w->succ, 4 * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(&first_leaf, w->first_leaf, 8, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(&best, w->best, 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s) || hipGetLastError()) {
+    hipLaunchKernelGGL(k_successor, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, w->succ);
+
+    std::vector<int> nlab(nb);
+    std::vector<LeafAcc> acc(nb * LGL_MAXL);
+    std::vector<unsigned long long> pres(nb * 512), first_leaf(nb), best(nb);
+    std::vector<SelState> st(nb * LGL_MAXL);
+    std::vector<uint32_t> succ(nb * LGL_MAXL);
+    if (hipMemcpyAsync(nlab.data(), w->nlab, nb * 4, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(acc.data(), w->acc, nb * sizeof(LeafAcc) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(pres.data(), w->pres, nb * 512 * 8, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(st.data(), w->st, nb * sizeof(SelState) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(succ.data(), w->succ, nb * 4 * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(first_leaf.data(), w->first_leaf, nb * 8, hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(best.data(), w->best, nb * 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s) || hipGetLastError()) {
         *err = "lg_leaf_stats: device copy / kernel failed";
         return LG_ERR_HIP;
     }
-    // ids in ascending order = slots in ascending order
-    int slot = 0;
-    for (int wi = 0; wi < 512 && slot < nlab; wi++) {
-        unsigned long long bits = pres[wi];
-        while (bits && slot < nlab) {
-            int b = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            lg_leaf_stat& o = stats[slot];
-            memset(&o, 0, sizeof(o));
-            o.id = wi * 64 + b;
-            o.area = (int32_t)acc[slot].area;
-            o.touches_border = acc[slot].border;
-            o.sum_x = (double)acc[slot].sum_x;
-            o.sum_y = (double)acc[slot].sum_y;
-            o.sum_depth = acc[slot].sum_depth;
-            o.sum_ray = acc[slot].sum_ray;
-            // np.median: odd n -> middle element; even n -> float32 mean of the two middle elements
-            auto k2f = [](uint32_t k) { uint32_t bb = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float fv; memcpy(&fv, &bb, 4); return fv; };
-            float lo = k2f(st[slot].key);
-            if (acc[slot].area % 2 == 1) {
-                o.median_depth = lo;
-            } else {
-                float hi = (st[slot].n_le > 0) ? lo : k2f(succ[slot]);  // duplicates of the key cover the upper index
-                float sum = lo + hi;                                     // float32 add, then /2 (np.mean of 2 float32)
-                o.median_depth = sum / 2.0f;
+    int worst = LG_OK;
+    for (int b = 0; b < B; b++) {
+        const int nl = nlab[b];
+        lg_leaf_stat* fstats = stats + (size_t)b * max_leaves;
+        int32_t* ext = extrema + 4 * (size_t)b;
+        n_leaves[b] = 0;
+        ext[0] = ext[1] = ext[2] = ext[3] = 0;
+        int fs = LG_OK;
+        if (nl > LGL_MAXL) { *err = "lg_leaf_stats: more than 64 distinct leaf labels in one frame"; fs = LG_ERR_UNSUPPORTED; }
+        else if (nl > max_leaves) { *err = "lg_leaf_stats: stats capacity too small"; fs = LG_ERR_INVALID; }
+        if (status) status[b] = fs;
+        if (fs) { worst = fs; continue; }
+        const LeafAcc* facc = &acc[(size_t)b * LGL_MAXL];
+        const SelState* fst = &st[(size_t)b * LGL_MAXL];
+        const uint32_t* fsucc = &succ[(size_t)b * LGL_MAXL];
+        // ids in ascending order = slots in ascending order
+        int slot = 0;
+        for (int wi = 0; wi < 512 && slot < nl; wi++) {
+            unsigned long long bits = pres[(size_t)b * 512 + wi];
+            while (bits && slot < nl) {
+                int bb = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                lg_leaf_stat& o = fstats[slot];
+                memset(&o, 0, sizeof(o));
+                o.id = wi * 64 + bb;
+                o.area = (int32_t)facc[slot].area;
+                o.touches_border = facc[slot].border;
+                o.sum_x = (double)facc[slot].sum_x;
+                o.sum_y = (double)facc[slot].sum_y;
+                o.sum_depth = facc[slot].sum_depth;
+                o.sum_ray = facc[slot].sum_ray;
+                // np.median: odd n -> middle element; even n -> float32 mean of the two middle elements
+                auto k2f = [](uint32_t k) { uint32_t v = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float fv; memcpy(&fv, &v, 4); return fv; };
+                float lo = k2f(fst[slot].key);
+                if (facc[slot].area % 2 == 1) {
+                    o.median_depth = lo;
+                } else {
+                    float hi = (fst[slot].n_le > 0) ? lo : k2f(fsucc[slot]);  // duplicates of the key cover the upper index
+                    float sum = lo + hi;                                       // float32 add, then /2 (np.mean of 2 float32)
+                    o.median_depth = sum / 2.0f;
+                }
+                slot++;
             }
-            slot++;
+        }
+        n_leaves[b] = nl;
+        // extrema: argmin = first leaf pixel (row-major); argmax = farthest background pixel, first occurrence
+        if (first_leaf[b] != ~0ull) { ext[0] = (int32_t)(first_leaf[b] / W); ext[1] = (int32_t)(first_leaf[b] % W); }
+        if (best[b] != 0) {   // (no background pixel: the field is all zeros -> argmax index 0)
+            uint32_t idx = 0xFFFFFFFFu - (uint32_t)(best[b] & 0xFFFFFFFFull);
+            ext[2] = (int32_t)(idx / W); ext[3] = (int32_t)(idx % W);
         }
     }
-    *n_leaves = nlab;
-    // extrema: argmin = first leaf pixel (row-major); argmax = farthest background pixel, first occurrence
-    if (first_leaf == ~0ull) { extrema[0] = 0; extrema[1] = 0; }
-    else { extrema[0] = (int32_t)(first_leaf / W); extrema[1] = (int32_t)(first_leaf % W); }
-    if (best == 0) { extrema[2] = 0; extrema[3] = 0; }  // no background pixel: the field is all zeros -> argmax index 0
-    else {
-        uint32_t idx = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
-        extrema[2] = (int32_t)(idx / W); extrema[3] = (int32_t)(idx % W);
-    }
-    return LG_OK;
+    return status ? LG_OK : worst;
+}
+
+int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
+                lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, std::string* err) {
+    return lg_leaf_run_batch(w, labels, depth, 1, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, nullptr, s, err);
 }

@@ -87,11 +87,70 @@ class OptimalLeafSelector:
                             sum_ray=float(s.sum_ray), median_depth=np.float32(s.median_depth)))
         return out, ((int(ext[0]), int(ext[1])), (int(ext[2]), int(ext[3]))), (H, W)
 
+    def leaf_statistics_batch(self, mask_tensors, depth_tensors):
+        """B frames [B,H,W] per call (lg_leaf_stats_batch) -> list of (stats, extrema, (H, W)) or None for a frame the
+        library could not handle (more than 64 labels)."""
+        lab = torch.as_tensor(mask_tensors).to(self.device)
+        if lab.dtype != torch.int16:
+            lab = lab.to(torch.int16)
+        lab = lab.contiguous()
+        dep = torch.as_tensor(depth_tensors).to(self.device, torch.float32).contiguous()
+        B, H, W = lab.shape
+        stats = (LgLeafStat * (_MAX_LEAVES * B))()
+        n = (C.c_int * B)()
+        ext = (C.c_int32 * (4 * B))()
+        status = (C.c_int * B)()
+        with torch.cuda.device(self.device):
+            check(self._h, lib.lg_leaf_stats_batch(self._h, lab.data_ptr(), dep.data_ptr(), B, H, W,
+                                                   float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
+                                                   stats, _MAX_LEAVES, n, ext, status,
+                                                   _VP(torch.cuda.current_stream(self.device).cuda_stream)),
+                  "lg_leaf_stats_batch")
+        out = []
+        for b in range(B):
+            if status[b] != 0:
+                out.append(None)
+                continue
+            fs = []
+            for i in range(n[b]):
+                s = stats[b * _MAX_LEAVES + i]
+                fs.append(dict(id=int(s.id), area=int(s.area), touches_border=bool(s.touches_border),
+                               sum_x=float(s.sum_x), sum_y=float(s.sum_y), sum_depth=float(s.sum_depth),
+                               sum_ray=float(s.sum_ray), median_depth=np.float32(s.median_depth)))
+            e = ext[4 * b:4 * b + 4]
+            out.append((fs, ((int(e[0]), int(e[1])), (int(e[2]), int(e[3]))), (H, W)))
+        return out
+
+    def select_optimal_leaves_batch(self, mask_tensors, depth_tensors):
+        """select_optimal_leaf for B frames with ONE device pass sequence -> list of leaf ids (or None)."""
+        try:
+            per_frame = self.leaf_statistics_batch(mask_tensors, depth_tensors)
+        except Exception as e:  # noqa: BLE001
+            logerr(f"Error in leaf selection: {str(e)}")
+            return [None] * len(mask_tensors)
+        out, tall = [], []
+        for fr in per_frame:
+            if fr is None:
+                logerr("Error in leaf selection: unsupported frame (more than 64 labels)")
+                out.append(None)
+            else:
+                out.append(self._select_from_statistics(*fr))
+            tall.append(self.get_tall_leaves() if out[-1] is not None else [])
+        self._tall_leaves_batch = tall
+        return out
+
     # ------------------------------------------------------------------ the selection (:25-203)
     def select_optimal_leaf(self, mask_tensor, depth_tensor, return_debug=False):
         """Enhanced leaf selection with tall leaf consideration."""
         try:
-            stats, (min_global, max_global), (H, W) = self.leaf_statistics(mask_tensor, depth_tensor)
+            return self._select_from_statistics(*self.leaf_statistics(mask_tensor, depth_tensor), return_debug=return_debug)
+        except Exception as e:  # noqa: BLE001  (:201-203)
+            logerr(f"Error in leaf selection: {str(e)}")
+            return None
+
+    def _select_from_statistics(self, stats, extrema, shape, return_debug=False):
+        try:
+            (min_global, max_global), (H, W) = extrema, shape
             # torch.unique(mask)[1:] skips the smallest value (the background 0 when present, :32)
             total = sum(s["area"] for s in stats)
             if total == H * W and stats:

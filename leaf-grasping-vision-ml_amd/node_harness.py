@@ -71,3 +71,33 @@ class LeafGraspHarness:
         self.mask_callback(mask_data)
         self.depth_callback(depth_data)
         return self.select_optimal_leaf()
+
+    def process_batch(self, mask_frames, depth_frames):
+        """B frames of wire data ([B, H*W] or [B, H, W]) through the node's sequence with ONE leaf-selection pass sequence
+        (lg_leaf_stats_batch) and ONE grasp-selection call (lg_select_grasp) for all frames: the batched form of
+        select_optimal_leaf (:102-158).  Returns the list of CSV strings (None where the node would publish nothing)."""
+        m = np.asarray(mask_frames)
+        m = m.astype(np.uint16).view(np.int16) if m.dtype != np.int16 else m
+        B = m.shape[0]
+        mask_t = torch.from_numpy(np.ascontiguousarray(m)).reshape(B, self.height, self.width).to(self.device)
+        depth_t = torch.from_numpy(np.ascontiguousarray(np.asarray(depth_frames, dtype=np.float32))).reshape(
+            B, self.height, self.width).to(self.device)
+        return self.process_batch_device(mask_t, depth_t)
+
+    def process_batch_device(self, mask_t, depth_t):
+        """process_batch for label / depth tensors already on the device ([B,H,W] int16 / float32)."""
+        B = mask_t.shape[0]
+        ids = self.leaf_scorer.select_optimal_leaves_batch(mask_t, depth_t)
+        self.last_leaf_ids = ids
+        out = [None] * B
+        keep = [b for b in range(B) if ids[b] is not None]
+        if not keep:
+            return out
+        idt = torch.tensor([ids[b] for b in keep], dtype=mask_t.dtype, device=self.device).reshape(-1, 1, 1)
+        sel = torch.tensor(keep, device=self.device)
+        optimal = mask_t.index_select(0, sel) == idt                    # optimal_mask = (mask_tensor == optimal_leaf_id)
+        res = self.grasp_selector.select_grasp_points_batch(optimal, depth_t.index_select(0, sel))
+        for b, (p2, p3, pre) in zip(keep, res):
+            if p2 is not None:
+                out[b] = self.format_result(p2, p3, pre)
+        return out

@@ -150,3 +150,40 @@ def test_hybrid_grasp_selector_facade(L):
     hg2.select_grasp_point(None, cands, torch.from_numpy(depth).cuda())
     assert hg2.last_selection["leaf_id"] == cands[0]["leaf_id"]
     assert hg2.select_grasp_point(None, [], None) == (None, None, None)
+
+
+def test_leaf_selection_batch_equals_per_frame(L):
+    """lg_leaf_stats_batch / select_optimal_leaves_batch / LeafGraspHarness.process_batch: B frames per call give exactly
+    the per-frame results (statistics, extrema, chosen leaf, tall leaves, CSV)."""
+    H, W = 540, 720                                      # large enough for leaves above the 10000 px area threshold
+    frames = [O.synthetic_scene(H, W, 40 + i) for i in range(7)]
+    P = frames[0][2]
+    labels = np.stack([f[0] for f in frames]).astype(np.int16)
+    labels[5][:] = 0                                     # a frame without leaves
+    depths = np.stack([f[1] for f in frames])
+    ols = L.OptimalLeafSelector("cuda:0")
+    ols.set_camera_params(P)
+    lab_d, dep_d = torch.from_numpy(labels).cuda(), torch.from_numpy(depths).cuda()
+    batch = ols.leaf_statistics_batch(lab_d, dep_d)
+    for b in range(len(frames)):
+        single = ols.leaf_statistics(lab_d[b], dep_d[b])
+        assert batch[b][1] == single[1] and batch[b][2] == single[2]
+        assert len(batch[b][0]) == len(single[0])
+        for x, y in zip(batch[b][0], single[0]):
+            assert x["id"] == y["id"] and x["area"] == y["area"] and x["touches_border"] == y["touches_border"]
+            assert x["sum_x"] == y["sum_x"] and x["sum_y"] == y["sum_y"] and x["median_depth"] == y["median_depth"]
+            # f64 atomics: the accumulation order differs with the grid -> last-bit differences
+            assert abs(x["sum_depth"] - y["sum_depth"]) <= 1e-9 * abs(y["sum_depth"]) + 1e-12
+            assert abs(x["sum_ray"] - y["sum_ray"]) <= 1e-9 * abs(y["sum_ray"]) + 1e-12
+    ids = ols.select_optimal_leaves_batch(lab_d, dep_d)
+    want = [ols.select_optimal_leaf(lab_d[b], dep_d[b]) for b in range(len(frames))]
+    assert ids == want and ids[5] is None and any(i is not None for i in ids)
+    ref = O.RefOptimalLeafSelector()
+    ref.set_camera_params(P)
+    assert ids == [ref.select_optimal_leaf(labels[b], depths[b]) for b in range(len(frames))]
+    hz = L.LeafGraspHarness(H, W, "cuda:0", load_model=False)
+    hz.camera_info_callback(P.reshape(-1))
+    hz.grasp_selector.set_cnn_state_dict(O.cnn_closed_form_params(0))
+    csv_b = hz.process_batch(labels.astype(np.uint16).reshape(len(frames), -1), depths.reshape(len(frames), -1))
+    csv_s = [hz.process(labels[b].astype(np.uint16).reshape(-1), depths[b].reshape(-1)) for b in range(len(frames))]
+    assert csv_b == csv_s and csv_b[5] is None
