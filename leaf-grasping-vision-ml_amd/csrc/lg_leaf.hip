@@ -296,20 +296,21 @@ __global__ __launch_bounds__(256) void k_coldist(const int16_t* __restrict__ lab
 template <int WP2>  // padded power-of-two width
 __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, int H, int W,
                                                unsigned long long* __restrict__ best) {
-    __shared__ int s_g2[WP2];
-    __shared__ int s_opt[WP2 + 1];
+    // 16-bit LDS images (g <= 16384, columns < 8192): 8.5 KB per row-workgroup -> 18 resident rows per CU instead of 9;
+    // the pass is a chain of dependent LDS round trips, more rows in flight is what hides them
+    __shared__ uint16_t s_g[WP2];
+    __shared__ uint16_t s_opt[WP2 + 2];
     __shared__ int s_big[WP2 / 64 + 2];
     __shared__ int s_nbig;
     const int y = blockIdx.x, lane = threadIdx.x;
     g += (size_t)blockIdx.y * H * W;
     best += (size_t)blockIdx.y * H;     // per-row results: H x B same-address atomics would serialise at one L2 channel
     for (int x = lane; x < WP2; x += 64) {
-        int v = (x < W) ? (int)g[(size_t)y * W + x] : LGL_GINF;
-        s_g2[x] = v * v;
+        s_g[x] = (x < W) ? g[(size_t)y * W + x] : (uint16_t)LGL_GINF;
     }
     __syncthreads();
     unsigned long long mykey = 0;
-    auto cost = [&](int x, int xp) { int d = x - xp; return d * d + s_g2[xp]; };
+    auto cost = [&](int x, int xp) { const int d = x - xp, gv = (int)s_g[xp]; return d * d + gv * gv; };
     // level l solves positions p = (2i+1) * WP2 / 2^(l+1); neighbours p -/+ half are solved (or the borders)
     for (int half = WP2 / 2; half >= 1; half >>= 1) {
         const int nsub = WP2 / (2 * half);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
                         mykey = key > mykey ? key : mykey;
                     }
                 }
-                s_opt[p] = res;
+                s_opt[p] = (uint16_t)res;
             }
             __syncthreads();
             const int nbig = s_nbig;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void k_rowedt(const uint16_t* __restrict__ g, i
                     if (oc < bc || (oc == bc && ox < bx)) { bc = oc; bx = ox; }
                 }
                 if (lane == 0) {
-                    s_opt[p] = bx;
+                    s_opt[p] = (uint16_t)bx;
                     if (bc > 0) {
                         unsigned long long key = ((unsigned long long)(uint32_t)bc << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(y * W + p));
                         mykey = key > mykey ? key : mykey;
