@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU (each on its own handle, stream and host thread); >1 lets the "
                          "latency-bound sweeps of one batch run beside the CNN of another")
+    ap.add_argument("--node-steps", type=int, default=3,
+                    help="extra, untimed-for-the-headline leg: steps of the WHOLE node sequence (batched leaf selection + "
+                         "grasp selection) reported as `node_sequence` (0 = skip)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: print every step's wall time to stderr "
                                                             "(adds a device sync per step; not the headline mode)")
     args = ap.parse_args()
@@ -287,6 +290,31 @@ def main():
                           f"(restated NumPy/torch-CPU + C chamfer path, numpy argsort, 20 batch-1 CNN forwards; "
                           f"NumPy planes single-threaded, torch CPU ops on {CPU_BASELINE_THREADS} threads); "
                           f"os.cpu_count()={os.cpu_count()}"}
+        if world == 1 and args.node_steps > 0 and not args.no_cnn:
+            # secondary figure (never `value`): the node's whole per-frame sequence, leaf_grasp_node_v3.py:102-158 --
+            # OptimalLeafSelector over the int16 label image, then GraspPointSelector on the chosen leaf -- batched
+            try:
+                nb = min(B, 128)
+                scenes = [O.synthetic_scene(H, W, seed=100 + s) for s in range(min(nb, 4))]
+                lab = torch.from_numpy(np.stack([scenes[i % len(scenes)][0] for i in range(nb)]).astype(np.int16)).to(dev)
+                dep = torch.from_numpy(np.stack([scenes[i % len(scenes)][1] for i in range(nb)])).to(dev)
+                hz = L.LeafGraspHarness(H, W, dev, load_model=False)
+                hz.camera_info_callback(np.asarray(P).reshape(-1))
+                hz.grasp_selector.set_cnn_state_dict(params)
+                hz.process_batch_device(lab, dep)
+                torch.cuda.synchronize(dev)
+                t_n = time.perf_counter()
+                for _ in range(args.node_steps):
+                    csvs = hz.process_batch_device(lab, dep)
+                torch.cuda.synchronize(dev)
+                dt_n = time.perf_counter() - t_n
+                out["node_sequence"] = {"value": round(nb * args.node_steps / dt_n, 1), "unit": "frames/s",
+                                        "frames_per_step": nb, "steps": args.node_steps,
+                                        "results": sum(c is not None for c in csvs),
+                                        "what": "batched leaf selection (lg_leaf_stats_batch + host Pareto) + grasp "
+                                                "selection incl. CNN, int16 labels + depth resident in HBM"}
+            except Exception as e:  # noqa: BLE001
+                out["node_sequence"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
