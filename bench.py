@@ -123,7 +123,13 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal switch for single-GPU boxes: all ranks on device 0 over gloo (exercises the barrier / MAX-reduction /
+        # rank-0 reporting path; the real multi-GPU run uses one device per rank over RCCL)
+        if os.environ.get("LG_BENCH_ONE_DEVICE"):
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
