@@ -12,6 +12,8 @@ the nearest leaf pixel (arg-max with first-occurrence ties).  PARITY UNPINNED vs
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 import torch
 
@@ -25,13 +27,26 @@ _MAX_LEAVES = 64
 
 def pareto_mask_max(scores):
     """paretoset(scores, sense=['max']*k): non-dominated rows, first of identical rows kept
-    (paretoset 1.2.3 is not installed; leaf_scorer.py:158,163)."""
-    s = np.asarray(scores, np.float64)
-    n = len(s)
+    (paretoset 1.2.3 is not installed; leaf_scorer.py:158,163).  Plain-Python comparisons on the float64 values (the
+    per-frame host cost of the batched path is this function and its caller, not the device passes)."""
+    rows = np.asarray(scores, np.float64).tolist()
+    n = len(rows)
     keep = np.ones(n, bool)
     for i in range(n):
+        ri = rows[i]
         for j in range(n):
-            if i != j and np.all(s[j] >= s[i]) and (np.any(s[j] > s[i]) or j < i):
+            if i == j:
+                continue
+            rj = rows[j]
+            ge = True
+            gt = False
+            for a, b in zip(rj, ri):
+                if a < b:
+                    ge = False
+                    break
+                if a > b:
+                    gt = True
+            if ge and (gt or j < i):
                 keep[i] = False
                 break
     return keep
@@ -167,8 +182,9 @@ class OptimalLeafSelector:
                 if area < 10000:  # :79-81
                     continue
                 centroid = (s["sum_x"] / area, s["sum_y"] / area)  # :84-88
-                dist_to_min = np.sqrt((centroid[0] - min_global[1]) ** 2 + (centroid[1] - min_global[0]) ** 2)
-                dist_to_max = np.sqrt((centroid[0] - max_global[1]) ** 2 + (centroid[1] - max_global[0]) ** 2)
+                # (math.sqrt == np.sqrt bit for bit: both correctly rounded; np.exp below is kept, libm's exp may differ in the last ulp)
+                dist_to_min = math.sqrt((centroid[0] - min_global[1]) ** 2 + (centroid[1] - min_global[0]) ** 2)
+                dist_to_max = math.sqrt((centroid[0] - max_global[1]) ** 2 + (centroid[1] - max_global[0]) ** 2)
                 total_dist = dist_to_min + dist_to_max
                 clutter_score = dist_to_min / total_dist if total_dist > 0 else 0  # :91-101
                 mean_depth = np.float32(s["sum_depth"] / area)  # np.mean of float32 depths (:105-106)
@@ -178,8 +194,8 @@ class OptimalLeafSelector:
                 if s["touches_border"]:  # :277-306
                     visibility_score = 0.0
                 else:
-                    d = np.sqrt((centroid[0] - W / 2) ** 2 + (centroid[1] - H / 2) ** 2)
-                    visibility_score = 1.0 - d / np.sqrt((W / 2) ** 2 + (H / 2) ** 2)
+                    d = math.sqrt((centroid[0] - W / 2) ** 2 + (centroid[1] - H / 2) ** 2)
+                    visibility_score = 1.0 - d / math.sqrt((W / 2) ** 2 + (H / 2) ** 2)
                 candidates.append({
                     "leaf_id": s["id"],
                     "scores": np.array([clutter_score, distance_score, visibility_score], dtype=np.float64),
@@ -207,7 +223,8 @@ class OptimalLeafSelector:
                 best_score, best_leaf = float("-inf"), None
                 self._tall_leaves = tall_leaves
                 for c in pareto:
-                    ws = np.sum(weights * c["scores"])
+                    sc = c["scores"]   # np.sum of three float64 products adds them left to right
+                    ws = 0.35 * float(sc[0]) + 0.35 * float(sc[1]) + 0.3 * float(sc[2])
                     if ws > best_score:
                         best_score, best_leaf = ws, c["leaf_id"]
                 if return_debug:
