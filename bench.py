@@ -37,11 +37,11 @@ CPU_BASELINE_THREADS = 16  # one GPU's share of the box's host cores (torch intr
 
 
 def make_frames(B, H, W, n_distinct=4):
-    from oracle import lg_oracle as O  # synthetic scene generator only (inputs, not the measured path)
+    import synthetic_inputs as SI  # seeded scenes (inputs; the oracle is only touched by the cpu_baseline leg)
 
     masks, depths, P = [], [], None
     for s in range(min(B, n_distinct)):
-        labels, depth, P = O.synthetic_scene(H, W, seed=100 + s)
+        labels, depth, P = SI.synthetic_scene(H, W, seed=100 + s)
         masks.append(labels == 1)
         depths.append(depth)
     reps = (B + len(masks) - 1) // len(masks)
@@ -137,7 +137,7 @@ def main():
 
     import leafgrasp_amd as L
     from leafgrasp_amd._lib import lib
-    from oracle import lg_oracle as O  # closed-form CNN weights (inputs) + cpu_baseline leg only
+    import synthetic_inputs as SI  # seeded scenes + closed-form CNN weights (inputs)
 
     H, W, B = args.height, args.width, args.batch
     masks_np, depths_np, P = make_frames(B, H, W)
@@ -145,7 +145,7 @@ def main():
     depths = torch.from_numpy(depths_np).to(dev)
     import threading
 
-    params = O.cnn_closed_form_params(seed=0)
+    params = SI.cnn_closed_form_params(seed=0)
     sels = []
     for _ in range(max(1, args.inflight)):
         sel = L.GraspPointSelector(dev, load_model=False)
@@ -301,7 +301,7 @@ def main():
             # OptimalLeafSelector over the int16 label image, then GraspPointSelector on the chosen leaf -- batched
             try:
                 nb = min(B, 128)
-                scenes = [O.synthetic_scene(H, W, seed=100 + s) for s in range(min(nb, 4))]
+                scenes = [SI.synthetic_scene(H, W, seed=100 + s) for s in range(min(nb, 4))]
                 lab = torch.from_numpy(np.stack([scenes[i % len(scenes)][0] for i in range(nb)]).astype(np.int16)).to(dev)
                 dep = torch.from_numpy(np.stack([scenes[i % len(scenes)][1] for i in range(nb)])).to(dev)
                 hz = L.LeafGraspHarness(H, W, dev, load_model=False)

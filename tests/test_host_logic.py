@@ -62,6 +62,39 @@ def test_product_never_imports_the_oracle():
                 assert "lg_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
 
 
+def test_only_the_allowed_places_touch_the_oracle():
+    """oracle/ is the checker: outside tests/ only __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it
+    (tools/ and synthetic_inputs.py must not; bench.py draws its inputs from synthetic_inputs.py)."""
+    import ast
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                hits.append(node.lineno)
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+        return tree, hits
+
+    for root, dirs, files in os.walk(REPO):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__", ".pytest_cache")]
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(root, f)
+            tree, hits = oracle_imports(path)
+            rel = os.path.relpath(path, REPO)
+            if rel == "__graft_entry__.py":
+                fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "smoke"][0]
+                assert all(fn.lineno <= h <= fn.end_lineno for h in hits), rel
+            elif rel == "bench.py":
+                fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline"][0]
+                assert hits and all(fn.lineno <= h <= fn.end_lineno for h in hits), (rel, hits)
+            else:
+                assert not hits, (rel, hits)
+
+
 def test_image_processor_kernels(golden):
     ip = L.ImageProcessor(96, 128, 21, 5)
     np.testing.assert_array_equal(ip.get_kernel("gaussian", "cpu").numpy(), golden["gaussian"])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-frame latency of the leaf-selection stage (lg_leaf_stats + host Pareto) and of the whole ROS-free node
-sequence on one MI355X, next to the restated CPU path (oracle).  Usage: python tools/leaf_bench.py [H W]"""
+sequence on one MI355X, next to the restated CPU path (oracle).  Usage: python tests/tools/leaf_bench.py [H W]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import leafgrasp_amd as L  # noqa: E402
 from oracle import lg_oracle as O  # noqa: E402
 

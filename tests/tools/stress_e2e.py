@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """End-to-end sweep: GPU select_grasp_point / select_optimal_leaf vs the float64 CPU oracle over many seeds.
-Reports how often the float32 planes reorder near-tied candidates.  Usage: python tools/stress_e2e.py [n]"""
+Reports how often the float32 planes reorder near-tied candidates.  Usage: python tests/tools/stress_e2e.py [n]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import leafgrasp_amd as L  # noqa: E402
 from oracle import lg_oracle as O  # noqa: E402
 

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity sweep (many seeds / odd sizes / multi-component masks).
-Usage: python tools/stress_parity.py [n_cases]"""
+Usage: python tests/tools/stress_parity.py [n_cases]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import leafgrasp_amd as L  # noqa: E402
 from oracle import lg_oracle as O  # noqa: E402
 

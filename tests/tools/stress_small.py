@@ -2,9 +2,14 @@
 """Degenerate-size / degenerate-mask GPU-vs-oracle sweep of lg_score_maps: frames of 8..80 x 8..300 pixels (smaller than a
 plane tile or a sweep wave), single pixels, noise, rectangles, full-minus-one-pixel masks, bottom-half noise: distance map,
 the two sdf maxima (windowed sweeps + frame-border norm), theta, every plane and the validity mask.
-Usage: python tools/stress_small.py"""
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+Usage: python tests/tools/stress_small.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import leafgrasp_amd as L
 from oracle import lg_oracle as O
 sel = L.GraspPointSelector("cuda:0", load_model=False)

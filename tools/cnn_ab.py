@@ -5,7 +5,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import leafgrasp_amd as L
-from oracle import lg_oracle as O  # closed-form weights / synthetic patches (inputs only)
+import synthetic_inputs as O  # seeded inputs only (closed-form weights / scenes / patches)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
 sel = L.GraspPointSelector(torch.device("cuda", 0), load_model=False)

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import leafgrasp_amd as L  # noqa: E402
-from oracle import lg_oracle as O  # noqa: E402
+import synthetic_inputs as O  # seeded inputs only (closed-form weights / scenes / patches)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 H, W = 1080, 1920
