@@ -207,11 +207,17 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 //   * B operand  V[ci][tile][16 (+4 pad)]: input chunk of 8 channels streamed by global_load_lds into a 2-stage
 //     LDS ring, transformed by thread (ci, tile) = (t>>5, t&31) with 8 ds_read_b64 + 32 adds + 4 ds_write_b128,
 //     read back as 4 ds_read_b128 per tile half (row stride 80 B: conflict free).
-template <int CIN, int COUT, int WI, bool POOL>
-__global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
+// WAVES = 4 (default): 256 threads, 64 output channels, chunks of 8 input channels, 2 workgroups per CU.
+// WAVES = 8 (LG_CNN_WIDE=1, layers with >= 128 output channels): 512 threads, 128 output channels share one transformed
+// tile block, chunks of 16 input channels, 1 workgroup per CU -- half the staging + transform work per MFMA.
+template <int CIN, int COUT, int WI, bool POOL, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        const float* __restrict__ zero_tail, int N, int ntb) {
-    constexpr int KC = 8;                                  // input channels per chunk (2 MFMA k-steps)
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int KC = 2 * WAVES;                          // input channels per chunk: one (channel, tile) item per thread
+    constexpr int KS = KC / 4;                             // MFMA k-steps per chunk
+    constexpr int CB = 16 * WAVES;                         // output channels per workgroup
     constexpr int TC = WI / 2, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup (8x8 images: 2)
     constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // workgroups (row bands) per patch
@@ -219,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     constexpr int TROWS = TPB / TC;                        // tile rows per band
     constexpr int RH = 2 * TROWS + 2, RW = WI + 2;         // staged input region (halo 1) per channel and patch
     constexpr int RS = RH * RW, S = PB * RS;
-    constexpr int NIN = (KC * S + 255) / 256;
+    constexpr int NIN = (KC * S + THREADS - 1) / THREADS;
     constexpr int VS = 20;                                 // floats per (ci, tile) row of V: 16 positions + 4 pad
-    constexpr int NCB = COUT / 64;
+    constexpr int NCB = COUT / CB;
     constexpr int NC = CIN / KC;
-    static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (RW % 2) == 0 && (RS % 2) == 0, "shape");
+    static_assert(CIN % KC == 0 && COUT % CB == 0 && TPB % TC == 0 && (RW % 2) == 0 && (RS % 2) == 0 && KS % 2 == 0, "shape");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float s_mem[2 * NIN * 256 + KC * 32 * VS];
-    float* const s_v = s_mem + 2 * NIN * 256;
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * NIN * THREADS + KC * 32 * VS];
+    float* const s_v = s_mem + 2 * NIN * THREADS;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) stay on the SALU
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     const int n0 = PB > 1 ? tb * PB : tb / BPP;
     const int band = PB > 1 ? 0 : tb % BPP;
     const int y0 = band * 2 * TROWS;                       // first output row of the band
-    const int co0 = cb * 64;
+    const int co0 = cb * CB;
 
     // ---- input staging: chunk-invariant 32-bit byte offsets from a wave-uniform base that advances per chunk
     //      (global_load_lds saddr + voffset form: issuing a chunk costs ~3 instructions per load).  Conv padding and
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     unsigned voff[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
-        const int e = t + 256 * j;
+        const int e = t + THREADS * j;
         const int ci = e / S, r = e % S;
         const int pb = r / RS, r2 = r % RS;
         const int ry = r2 / RW, rx = r2 % RW;
@@ -263,11 +269,11 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     }
     auto issue_input = [&](int c, int stage) {
         const char* in_c = (const char*)(in_n + (size_t)c * KC * WI * WI);
-        float* sb = s_mem + stage * (NIN * 256);
+        float* sb = s_mem + stage * (NIN * THREADS);
 #pragma unroll
         for (int j = 0; j < NIN; j++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in_c + voff[j]),
-                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sb + THREADS * j + 64 * wave), 4, 0, 0);
     };
     // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co]
     const float* u_lane = U + ((size_t)(lane >> 4) * COUT + co0 + 16 * wave + (lane & 15)) * 16;
@@ -315,16 +321,16 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
         }
     };
 
-    f32x4 a0[4], a1[4];
+    f32x4 ab[2][4];   // A operand ring: k-step ksl of a chunk uses ab[ksl & 1]
     issue_input(0, 0);
-    load_u(0, a0);
+    load_u(0, ab[0]);
 #pragma unroll 1
     for (int c = 0; c < NC; c++) {
-        __syncthreads();                                   // vmcnt(0): input(c) + a0 landed; V / other stage free
-        load_u(2 * c + 1, a1);
+        __syncthreads();                                   // vmcnt(0): input(c) + ab[0] landed; V / other stage free
+        load_u(KS * c + 1, ab[1]);
         if (c + 1 < NC) issue_input(c + 1, (c + 1) & 1);
         {   // V = B^T d B for (tci, tau)
-            const float* sp = s_mem + (c & 1) * (NIN * 256) + tsrc;
+            const float* sp = s_mem + (c & 1) * (NIN * THREADS) + tsrc;
             // packed-f32 form: rows as (lo, hi) pairs; the column step folds its negations / half selections into
             // v_pk_add_f32 modifiers instead of moves
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -356,10 +362,17 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V visible; does not drain the prefetches
-        mfma_step(0, a0, [] {});
-        // prefetch of the next chunk's first k-step, pinned behind the first MFMAs of this one: hipcc waits with
-        // vmcnt(0) for a1, and sinks an unpinned prefetch to the loop end where the barrier's vmcnt(0) exposes it
-        mfma_step(1, a1, [&] { load_u(2 * c + 2 < 2 * NC ? 2 * c + 2 : 2 * NC - 1, a0); });
+        // A operand of k-step ksl + 1 (the next chunk's first one at the end), requested behind the first MFMAs of step
+        // ksl >= 1 into the buffer step ksl - 1 has released: hipcc waits with vmcnt(0) for the buffer in use, and sinks
+        // an unpinned prefetch to the loop end where the barrier's vmcnt(0) exposes it
+#pragma unroll
+        for (int ksl = 0; ksl < KS; ksl++)
+            mfma_step(ksl, ab[ksl & 1], [&] {
+                if (ksl >= 1) {
+                    const int ksn = KS * c + ksl + 1;
+                    load_u(ksn < KS * NC ? ksn : KS * NC - 1, ab[(ksl + 1) & 1]);
+                }
+            });
     }
 
     // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile), planar NCHW store
@@ -791,10 +804,24 @@ bool wino_supported(int cin, int cout, int wi, bool pool) {
     return false;
 }
 
+// 128 output channels per workgroup (WAVES = 8): the layers of the default encoder with >= 128 output channels
+#define LG_WINO_WIDE_SHAPES(X) X(64, 128, 16, false) X(128, 128, 16, true) X(128, 256, 8, false) X(256, 256, 8, true)
+
 bool launch_wino_rt(int cin, int cout, int wi, bool pool, const float* in, const float* U, const float* bias, float* out,
                     const float* zero_tail, int N, hipStream_t s) {
     const int tp = (wi / 2) * (wi / 2);
     const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
+    if (getenv("LG_CNN_WIDE")) {
+        const int gridw = ntb * (cout / 128);
+#define X(CI, CO, W_, P)                                                                                           \
+    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                        \
+        hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P, 8>), dim3(gridw), dim3(512), 0, s, in, U, bias, out, zero_tail, \
+                           N, ntb);                                                                                \
+        return true;                                                                                               \
+    }
+        LG_WINO_WIDE_SHAPES(X)
+#undef X
+    }
     const int grid = ntb * (cout / 64);
 #define X(CI, CO, W_, P)                                                                                           \
     if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                        \

@@ -284,6 +284,11 @@ def test_cnn_winograd_matches_direct(sel, monkeypatch):
     for n in (41, 1, 2, 7):
         np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"ws kernel n {n}")
     monkeypatch.delenv("LG_CNN_WS_KC")
+    # ... and the 8-wave / 128-output-channel form of the lock-step kernel (LG_CNN_WIDE=1)
+    monkeypatch.setenv("LG_CNN_WIDE", "1")
+    for n in (41, 1, 2, 7):
+        np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"wide kernel n {n}")
+    monkeypatch.delenv("LG_CNN_WIDE")
     sel.clear_cnn()
 
 
