@@ -192,6 +192,113 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Layer 0 (9 input channels, 32x32, no pool) as a workgroup per (patch, 64 output channels) that walks the four 8-row
+// bands of its patch: the 23 KB weight image is staged once instead of once per band and the next band's input streams
+// into the other LDS stage while the current one is multiplied -- the generic kernel above, launched per band, spent
+// 0.43 of this layer's time on the staging round trip of a 180-MFMA workgroup (MFMA busy 0.57).
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int CIN = 9, CINP = 10, WI = 32, ROWS = 8, TR = ROWS + 2, TWID = WI + 2, BANDS = WI / ROWS;
+    constexpr int IN_CH_STRIDE = TR * TWID;
+    constexpr int IN_ELEMS = CINP * TR * TWID;
+    constexpr int NIN = (IN_ELEMS + 255) / 256;
+    constexpr int IN_PAD = NIN * 256;
+    constexpr int W4_ELEMS = 9 * CINP * (64 / 4);
+    constexpr int NW4 = (W4_ELEMS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float s_buf[2 * IN_PAD + NW4 * 256 * 4];   // [input stage 0 | stage 1 | weights]
+    float* const s_w = s_buf + 2 * IN_PAD;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // pixel-block pair of this wave: band rows 2w, 2w+1
+    const int n = blockIdx.x / (COUT / 64), co0 = (blockIdx.x % (COUT / 64)) * 64;
+    const int p = lane & 31, kh = lane >> 5;
+    const int boff0 = (2 * wave) * TWID + p, boff1 = (2 * wave + 1) * TWID + p;
+    const int aoff = lane & 31;
+    const float* in_n = in + (size_t)n * CIN * WI * WI;
+
+    // staging slots: (channel, row of the band window, column); the row decides validity per band
+    int off0[NIN], ry_[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int idx = t + 256 * j;
+        const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
+        const int ry = r2 / TWID, gx = r2 % TWID - 1;
+        const bool okx = idx < IN_ELEMS && ci < CIN && gx >= 0 && gx < WI;
+        off0[j] = (ci * WI + ry - 1) * WI + gx;           // band 0; + ROWS * WI per band
+        ry_[j] = okx ? ry : -1000;                        // never valid
+    }
+    auto issue_input = [&](int band, int stage) {
+        float* sb = s_buf + stage * IN_PAD;
+#pragma unroll
+        for (int j = 0; j < NIN; j++) {
+            const int gy = band * ROWS - 1 + ry_[j];
+            const float* src = (gy >= 0 && gy < WI) ? in_n + off0[j] + band * ROWS * WI : lg_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NW4; j++) {   // weights once: [tap][ci][64 channels], 16 bytes per lane
+        const int idx = t + 256 * j;
+        const int q = idx % 16, rest = idx / 16;
+        const int ci = rest % CINP, tap = rest / CINP;
+        const float* src = idx < W4_ELEMS ? wp + ((size_t)tap * CINP + ci) * COUT + co0 + 4 * q : lg_zero_pad;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(s_w + 4 * (256 * j + 64 * wave)), 16, 0, 0);
+    }
+    issue_input(0, 0);
+    float bv[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) bv[j][r] = bias[co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+
+#pragma unroll 1
+    for (int band = 0; band < BANDS; band++) {
+        __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
+        if (band + 1 < BANDS) issue_input(band + 1, (band + 1) & 1);
+        const float* s_in = s_buf + (band & 1) * IN_PAD;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int k0 = 0; k0 < CINP; k0 += 2) {
+                const int ci = k0 + kh;
+                const float a0 = s_w[(tap * CINP + ci) * 64 + aoff];
+                const float a1 = s_w[(tap * CINP + ci) * 64 + aoff + 32];
+                const float b0 = s_in[ci * IN_CH_STRIDE + boff0 + ky * TWID + kx];
+                const float b1 = s_in[ci * IN_CH_STRIDE + boff1 + ky * TWID + kx];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        // bias + ReLU, one 128-byte row segment per (channel, row) and store instruction
+        float* out_n = out + (size_t)n * COUT * WI * WI;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int y = band * ROWS + 2 * wave + i;
+                    out_n[((size_t)co * WI + y) * WI + p] = fmaxf(acc[i][j][r] + bv[j][r], 0.0f);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) form of the same 3x3 convolutions (layers 1..5; layer 0 has 9 input channels and stays
 // direct):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input tile d / 2x2 output tile Y, i.e. 16 independent
 // contractions over the input channels instead of 36 multiply-adds per output pair: 2.25x fewer MFMA flops,
@@ -770,12 +877,17 @@ void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t
                        s, in, c->wconv[L], c->bconv[L], out);
 }
 
-// layer 0 of any encoder (9 input channels -> 64 or 128 padded output channels at 32x32): direct implicit GEMM
+// layer 0 of any encoder (9 input channels -> 64 or 128 padded output channels at 32x32): direct implicit GEMM,
+// one workgroup per (patch, 64 channels) walking the four bands (LG_CNN_L0_BANDS=1: the per-band generic kernel, A/B)
 template <int COUT>
 void launch_conv0(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
-    const int grid = N * 4 * (COUT / 64);   // PP = 4: 8 rows per workgroup -> 4 bands
-    hipLaunchKernelGGL((lg_conv3x3_kernel<9, 10, COUT, 32, false, 10, 4, 1>), dim3(grid), dim3(256), 0, s, in, c->wconv[0],
-                       c->bconv[0], out);
+    if (getenv("LG_CNN_L0_BANDS")) {
+        const int grid = N * 4 * (COUT / 64);   // PP = 4: 8 rows per workgroup -> 4 bands
+        hipLaunchKernelGGL((lg_conv3x3_kernel<9, 10, COUT, 32, false, 10, 4, 1>), dim3(grid), dim3(256), 0, s, in, c->wconv[0],
+                           c->bconv[0], out);
+        return;
+    }
+    hipLaunchKernelGGL((lg_conv0_kernel<COUT>), dim3(N * (COUT / 64)), dim3(256), 0, s, in, c->wconv[0], c->bconv[0], out);
 }
 
 template <int L, int KC>
