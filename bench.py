@@ -282,7 +282,7 @@ def main():
                                                                              + 256 * 128 * 16 + 256 * 256 * 16))
             sec = kern["cnn"]["avg_ms"] * 1e-3
             tf = exec_fl * 20 * B / sec / 1e12
-            out["mfma"] = {"kernel": "lg_conv3x3_kernel (layer 0) + lg_wino_kernel x5 (Winograd F(2x2,3x3)) + head"
+            out["mfma"] = {"kernel": "lg_conv0_kernel (layer 0) + lg_wino_kernel x5 (Winograd F(2x2,3x3)) + head"
                                      if not direct else "lg_conv3x3_kernel x6 + head",
                            "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                            "executed_mflop_per_patch": round(exec_fl / 1e6, 2),
