@@ -221,6 +221,37 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
    win[0..3] (optional) = the distance-transform sweep window {x0, x1, y0, y1} (half open) used for that frame. */
 int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]);
 
+/* ---- GraspPointCNN training step: one call = one iteration of the inner loop of
+   scripts/train_model.py:247-265 (zero_grad, forward in train mode, BCEWithLogitsLoss(pos_weight), backward,
+   clip_grad_norm_(max_grad_norm), Adam step with L2 weight_decay) on the model of
+   scripts/utils/ml_grasp_optimizer/model.py:5-128 with attention LG_ATT_SPATIAL (the script's model) or LG_ATT_NONE.
+   Flat parameter vector = model.parameters() order; flat buffer vector = running_mean, running_var of every BatchNorm
+   in module order.  Dropout keep masks: one [N][width] block per dropout layer, concatenated in module order
+   (Dropout2d of every encoder block: width = filters[b]; classifier Dropout 0.5 / 0.5 / 0.4: widths F, F/2, F/4),
+   values 0 or 1/(1-p); NULL = drawn on the device from `seed` and the step counter. */
+typedef struct lg_trainer lg_trainer;
+typedef struct lg_train_hparams {
+    float lr, beta1, beta2, eps, weight_decay;   /* train_model.py:222: Adam(lr=0.0005, weight_decay=0.01), betas (0.9, 0.999), eps 1e-8 */
+    float max_grad_norm;                         /* :256 clip_grad_norm_(max_norm=1.0); <= 0: no clipping */
+    float pos_weight;                            /* :221 BCEWithLogitsLoss(pos_weight=2.0) */
+} lg_train_hparams;
+int lg_train_create(int device, int n_blocks, const int32_t* filters, int attention_type, int max_batch, lg_trainer** out);
+int lg_train_destroy(lg_trainer* t);
+const char* lg_train_last_error(lg_trainer* t);
+int lg_train_sizes(lg_trainer* t, int64_t* n_params, int64_t* n_buffers, int64_t* mask_row);
+/* HOST arrays; exp_avg / exp_avg_sq may be NULL (= zeros: a fresh optimizer) */
+int lg_train_set_state(lg_trainer* t, const float* params, const float* buffers, const float* exp_avg,
+                       const float* exp_avg_sq, int64_t step);
+/* HOST arrays, any may be NULL; grads = the unclipped gradients of the last step */
+int lg_train_get_state(lg_trainer* t, float* params, float* buffers, float* exp_avg, float* exp_avg_sq, float* grads,
+                       int64_t* step);
+/* x [N][9][32][32], labels [N], masks (or NULL), logits_dev (or NULL): DEVICE pointers.  apply_update = 0: loss and
+   gradients only (BatchNorm running statistics still move, as in a train-mode forward).  loss_host / grad_norm_host
+   (or NULL) make the call synchronous. */
+int lg_train_step(lg_trainer* t, const float* x, const float* labels, int N, const float* masks, uint64_t seed,
+                  const lg_train_hparams* hp, int apply_update, float* loss_host, float* grad_norm_host, float* logits_dev);
+int lg_train_sync(lg_trainer* t);
+
 #ifdef __cplusplus
 }
 #endif

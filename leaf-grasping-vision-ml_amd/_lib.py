@@ -42,6 +42,12 @@ class LgGraspResult(C.Structure):
                 ("best_score", C.c_float), ("theta", C.c_float)]
 
 
+class LgTrainHparams(C.Structure):
+    """lg_train_hparams; defaults = scripts/train_model.py:221-222,256."""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("pos_weight", C.c_float)]
+
+
 class LgLeafStat(C.Structure):
     _fields_ = [("id", C.c_int32), ("area", C.c_int32), ("touches_border", C.c_int32), ("pad_", C.c_int32),
                 ("sum_x", C.c_double), ("sum_y", C.c_double), ("sum_depth", C.c_double), ("sum_ray", C.c_double),
@@ -78,6 +84,14 @@ SYMBOLS = {
     "lg_harvest_patches": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "lg_negative_masks": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "lg_leaf_contour": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP, C.c_int, C.POINTER(C.c_int), _VP]),
+    "lg_train_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(_VP)]),
+    "lg_train_destroy": (C.c_int, [_VP]),
+    "lg_train_last_error": (C.c_char_p, [_VP]),
+    "lg_train_sizes": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "lg_train_set_state": (C.c_int, [_VP, _FP, _FP, _FP, _FP, C.c_int64]),
+    "lg_train_get_state": (C.c_int, [_VP, _FP, _FP, _FP, _FP, _FP, C.POINTER(C.c_int64)]),
+    "lg_train_step": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_uint64, C.POINTER(LgTrainHparams), C.c_int, _FP, _FP, _VP]),
+    "lg_train_sync": (C.c_int, [_VP]),
 }
 
 

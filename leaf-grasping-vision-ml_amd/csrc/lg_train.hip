@@ -1,0 +1,1006 @@
+// GraspPointCNN training step on gfx950: forward in train mode (batch-statistics BatchNorm, Dropout2d / Dropout with
+// explicit keep masks), BCEWithLogits(pos_weight) loss, backward, global-norm gradient clipping and Adam with L2 weight
+// decay -- one call = one iteration of the inner loop of scripts/train_model.py:247-265 on the model of
+// scripts/utils/ml_grasp_optimizer/model.py:5-128 (attention 'spatial' = the script's default, or 'none';
+// any encoder_filters of the reference's sweep).
+//
+// Convolutions (forward, backward-data, backward-weights) run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation) as implicit GEMMs whose operands are gathered per lane from an LDS-staged halo tile:
+//   forward / backward-data : M = output channel, N = pixel, K = (tap, input channel)
+//   backward-weights        : M = input channel,  N = output channel, K = pixel, one accumulator per tap; split over
+//                             pixel tiles into partial sums that a second kernel adds in a fixed order (deterministic).
+// The pixel index runs over (sample, y, x), so small feature maps (8x8, 4x4) fill a tile with several samples.
+// Everything else (BN statistics / apply / backward, pooling, attention, classifier, loss, optimizer) is HBM- or
+// latency-bound elementwise / reduction work; all reductions are ordered, two runs give identical bits.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/leafgrasp.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ tiles
+template <int WI, int TILE>
+struct Tile {
+    static constexpr int HW = WI * WI;
+    static constexpr int TS = HW >= TILE ? 1 : TILE / HW;   // samples per tile
+    static constexpr int TR = HW >= TILE ? TILE / WI : WI;  // image rows per tile
+    static constexpr int BANDS = WI / TR;
+    static constexpr int TW = WI + 2, TH = TR + 2;          // staged rows / columns (halo 1)
+    static constexpr int PLANE = TS * TH * TW;              // staged floats per channel
+    __device__ static int halo(int q) {                     // offset of the 3x3 window's top-left for tile pixel q
+        const int ts = q / (TR * WI), row = (q / WI) % TR, x = q % WI;
+        return (ts * TH + row) * TW + x;
+    }
+};
+
+__device__ inline float block_sum(float v, float* s_red) {   // 256 threads; result in every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ conv fwd / dgrad
+// out[n][co][y][x] = bias[co] + sum_{tap,ci} wp[tap][ci][co] * in[n][ci][y+ky-1][x+kx-1]     (zero padding)
+// Workgroup: 256 pixels x 64 output channels; wave: 64 pixels x 64 channels (2 x 2 accumulators).
+template <int WI>
+__global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                       int CI, int CO) {
+    using T = Tile<WI, 256>;
+    constexpr int KC = 8;
+    constexpr int NIN = (KC * T::PLANE + 255) / 256, NWT = 9 * KC * 64 / 256;
+    __shared__ float s_in[KC * T::PLANE];
+    __shared__ float s_w[9 * KC * 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
+    const int tile = blockIdx.x, n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR, co0 = blockIdx.y * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    int boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) boff[i] = T::halo(wave * 64 + i * 32 + lm);
+
+    // chunk-invariant source offsets of this thread's staging slots
+    int off_in[NIN], ci_in[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int idx = t + 256 * j, ci = idx / T::PLANE, r = idx % T::PLANE;
+        const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
+        const int gy = y0 - 1 + ry, gx = rx - 1, n = n0 + ts;
+        const bool ok = idx < KC * T::PLANE && n < N && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
+        off_in[j] = ok ? ((n * CI + ci) * WI + gy) * WI + gx : -1;
+        ci_in[j] = ci;
+    }
+    float r_in[NIN], r_w[NWT];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NIN; j++)
+            r_in[j] = (off_in[j] >= 0 && c0 + ci_in[j] < CI) ? in[(size_t)off_in[j] + (size_t)c0 * WI * WI] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NWT; j++) {
+            const int idx = t + 256 * j, co = idx & 63, rest = idx >> 6, ci = rest % KC, tap = rest / KC;
+            r_w[j] = (c0 + ci < CI && co0 + co < CO) ? wp[((size_t)tap * CI + c0 + ci) * CO + co0 + co] : 0.0f;
+        }
+    };
+    load_chunk(0);
+    for (int c0 = 0; c0 < CI; c0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NIN; j++)
+            if (t + 256 * j < KC * T::PLANE) s_in[t + 256 * j] = r_in[j];
+#pragma unroll
+        for (int j = 0; j < NWT; j++) s_w[t + 256 * j] = r_w[j];
+        __syncthreads();
+        if (c0 + KC < CI) load_chunk(c0 + KC);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int k0 = 0; k0 < KC; k0 += 2) {
+                const int ci = k0 + kh;
+                const float a0 = s_w[(tap * KC + ci) * 64 + lm];
+                const float a1 = s_w[(tap * KC + ci) * 64 + lm + 32];
+                const float b0 = s_in[ci * T::PLANE + boff[0] + ky * T::TW + kx];
+                const float b1 = s_in[ci * T::PLANE + boff[1] + ky * T::TW + kx];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = wave * 64 + i * 32 + lm;
+        const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < CO) out[(((size_t)n * CO + co) * WI + y) * WI + x] = acc[i][j][r] + (bias ? bias[co] : 0.0f);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv wgrad
+// partial[s][tap][ci][co] = sum over the pixel tiles of slice s of a[n][ci][y+ky-1][x+kx-1] * dx[n][co][y][x]
+// Workgroup: 64 ci x 64 co (wave: 32 x 32, nine tap accumulators), 128 pixels per K tile.
+template <int WI>
+__global__ __launch_bounds__(256) void lgt_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dx,
+                                                        float* __restrict__ partial, int N, int CI, int CO, int ntiles) {
+    using T = Tile<WI, 128>;
+    constexpr int SD = 129, SI = T::PLANE | 1;
+    __shared__ float s_d[64 * SD];
+    __shared__ float s_i[64 * SI];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
+    const int wc = wave & 1, wi = wave >> 1;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const bool active = ci0 + wi * 32 < CI && co0 + wc * 32 < CO;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR;
+        __syncthreads();
+        for (int idx = t; idx < 64 * 128; idx += 256) {
+            const int co = idx >> 7, q = idx & 127;
+            const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
+            s_d[co * SD + q] = (n < N && co0 + co < CO) ? dx[(((size_t)n * CO + co0 + co) * WI + y) * WI + x] : 0.0f;
+        }
+        for (int idx = t; idx < 64 * T::PLANE; idx += 256) {
+            const int ci = idx / T::PLANE, r = idx % T::PLANE;
+            const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
+            const int gy = y0 - 1 + ry, gx = rx - 1, n = n0 + ts;
+            const bool ok = n < N && ci0 + ci < CI && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
+            s_i[ci * SI + r] = ok ? a[(((size_t)n * CI + ci0 + ci) * WI + gy) * WI + gx] : 0.0f;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 4
+            for (int q0 = 0; q0 < 128; q0 += 2) {
+                const int q = q0 + kh;
+                const float b = s_d[(wc * 32 + lm) * SD + q];
+                const float* ai = s_i + (wi * 32 + lm) * SI + T::halo(q);
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[(tap / 3) * T::TW + tap % 3], b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    const int co = co0 + wc * 32 + lm;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (ci < CI && co < CO) partial[(((size_t)blockIdx.x * 9 + tap) * CI + ci) * CO + co] = acc[tap][r];
+        }
+}
+
+// gw[co][ci][tap] = sum_s partial[s][tap][ci][co]   (fixed order)
+__global__ void lgt_wreduce_kernel(const float* __restrict__ partial, int S, int CI, int CO, float* __restrict__ gw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, n = 9 * CI * CO;
+    if (e >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < S; k++) s += partial[(size_t)k * n + e];
+    const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+    gw[((size_t)co * CI + ci) * 9 + tap] = s;
+}
+
+// w[co][ci][tap] -> wpf[tap][ci][co] (forward) and wpd[8-tap][co][ci] (backward-data: taps mirrored, channels swapped)
+__global__ void lgt_pack_kernel(const float* __restrict__ w, int CI, int CO, float* __restrict__ wpf,
+                                float* __restrict__ wpd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 9 * CI * CO) return;
+    const int tap = e % 9, ci = (e / 9) % CI, co = e / (9 * CI);
+    const float v = w[e];
+    wpf[((size_t)tap * CI + ci) * CO + co] = v;
+    wpd[((size_t)(8 - tap) * CO + co) * CI + ci] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm2d
+// one workgroup per channel: mean, biased variance (two passes), rstd; running statistics as nn.BatchNorm2d (momentum 0.1,
+// unbiased variance in the running estimate)
+__global__ __launch_bounds__(256) void lgt_bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, float eps,
+                                                           float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var) {
+    __shared__ float s_red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int M = N * HW;
+    float s = 0.0f;
+    for (int i = t; i < M; i += 256) s += x[((size_t)(i / HW) * C + c) * HW + i % HW];
+    const float mu = block_sum(s, s_red) / (float)M;
+    float v = 0.0f;
+    for (int i = t; i < M; i += 256) {
+        const float d = x[((size_t)(i / HW) * C + c) * HW + i % HW] - mu;
+        v += d * d;
+    }
+    const float var = block_sum(v, s_red) / (float)M;
+    if (t == 0) {
+        mean[c] = mu;
+        rstd[c] = 1.0f / sqrtf(var + eps);
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mu;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+    }
+}
+
+__device__ inline float bn_relu(float x, float mu, float rs, float g, float b) { return fmaxf((x - mu) * rs * g + b, 0.0f); }
+
+// first maximum of the 2x2 cell in row-major scan order (nn.MaxPool2d routes the gradient there)
+__device__ inline int argmax4(const float y[4]) {
+    int k = 0;
+    float m = y[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (y[i] > m) { m = y[i]; k = i; }
+    return k;
+}
+
+// out = relu(bn(x))                                   (POOL = false)
+// out = maxpool2x2(relu(bn(x))) * dmask[n][c]          (POOL = true: Dropout2d keep mask, already scaled by 1/(1-p))
+template <bool POOL>
+__global__ void lgt_bn_act_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ gam,
+                                  const float* __restrict__ bet, const float* __restrict__ dmask,
+                                  float* __restrict__ out, int N, int C, int WI) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!POOL) {
+        const int HW = WI * WI;
+        if (idx >= (size_t)N * C * HW) return;
+        const int c = (idx / HW) % C;
+        out[idx] = bn_relu(x[idx], mean[c], rstd[c], gam[c], bet[c]);
+    } else {
+        const int WO = WI / 2;
+        if (idx >= (size_t)N * C * WO * WO) return;
+        const int xo = idx % WO, yo = (idx / WO) % WO;
+        const size_t nc = idx / (WO * WO);
+        const int c = nc % C;
+        const float* xp = x + (nc * WI + 2 * yo) * WI + 2 * xo;
+        const float mu = mean[c], rs = rstd[c], g = gam[c], b = bet[c];
+        const float m = fmaxf(fmaxf(bn_relu(xp[0], mu, rs, g, b), bn_relu(xp[1], mu, rs, g, b)),
+                              fmaxf(bn_relu(xp[WI], mu, rs, g, b), bn_relu(xp[WI + 1], mu, rs, g, b)));
+        out[idx] = m * dmask[nc];
+    }
+}
+
+// dgamma[c] = sum dy * xhat, dbeta[c] = sum dy with dy = dout routed back through (dropout, max-pool,) ReLU
+template <bool POOL>
+__global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gam, const float* __restrict__ bet,
+                                                                const float* __restrict__ dmask, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int N, int C, int WI) {
+    __shared__ float s_red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float mu = mean[c], rs = rstd[c], g = gam[c], b = bet[c];
+    float sg = 0.0f, sb = 0.0f;
+    if (!POOL) {
+        const int HW = WI * WI, M = N * HW;
+        for (int i = t; i < M; i += 256) {
+            const size_t e = ((size_t)(i / HW) * C + c) * HW + i % HW;
+            const float xh = (x[e] - mu) * rs;
+            const float dy = (xh * g + b > 0.0f) ? dout[e] : 0.0f;
+            sg += dy * xh;
+            sb += dy;
+        }
+    } else {
+        const int WO = WI / 2, HWO = WO * WO, M = N * HWO;
+        for (int i = t; i < M; i += 256) {
+            const int n = i / HWO, r = i % HWO, yo = r / WO, xo = r % WO;
+            const size_t nc = (size_t)n * C + c;
+            const float* xp = x + (nc * WI + 2 * yo) * WI + 2 * xo;
+            const float xh[4] = {(xp[0] - mu) * rs, (xp[1] - mu) * rs, (xp[WI] - mu) * rs, (xp[WI + 1] - mu) * rs};
+            const float y[4] = {fmaxf(xh[0] * g + b, 0.0f), fmaxf(xh[1] * g + b, 0.0f), fmaxf(xh[2] * g + b, 0.0f),
+                                fmaxf(xh[3] * g + b, 0.0f)};
+            const int k = argmax4(y);
+            const float dy = y[k] > 0.0f ? dout[nc * HWO + r] * dmask[nc] : 0.0f;
+            sg += dy * xh[k];
+            sb += dy;
+        }
+    }
+    sg = block_sum(sg, s_red);
+    sb = block_sum(sb, s_red);
+    if (t == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+}
+
+// dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M)
+template <bool POOL>
+__global__ void lgt_bn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gam, const float* __restrict__ bet,
+                                     const float* __restrict__ dmask, const float* __restrict__ dgamma,
+                                     const float* __restrict__ dbeta, float* __restrict__ dx, int N, int C, int WI) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float invM = 1.0f / (float)(N * WI * WI);
+    if (!POOL) {
+        const int HW = WI * WI;
+        if (idx >= (size_t)N * C * HW) return;
+        const int c = (idx / HW) % C;
+        const float rs = rstd[c], g = gam[c];
+        const float xh = (x[idx] - mean[c]) * rs;
+        const float dy = (xh * g + bet[c] > 0.0f) ? dout[idx] : 0.0f;
+        dx[idx] = g * rs * (dy - dbeta[c] * invM - xh * dgamma[c] * invM);
+    } else {
+        const int WO = WI / 2;
+        if (idx >= (size_t)N * C * WO * WO) return;
+        const int xo = idx % WO, yo = (idx / WO) % WO;
+        const size_t nc = idx / (WO * WO);
+        const int c = nc % C;
+        const size_t e0 = (nc * WI + 2 * yo) * WI + 2 * xo;
+        const float mu = mean[c], rs = rstd[c], g = gam[c], b = bet[c];
+        const float xh[4] = {(x[e0] - mu) * rs, (x[e0 + 1] - mu) * rs, (x[e0 + WI] - mu) * rs, (x[e0 + WI + 1] - mu) * rs};
+        const float y[4] = {fmaxf(xh[0] * g + b, 0.0f), fmaxf(xh[1] * g + b, 0.0f), fmaxf(xh[2] * g + b, 0.0f),
+                            fmaxf(xh[3] * g + b, 0.0f)};
+        const int k = argmax4(y);
+        const float dyk = y[k] > 0.0f ? dout[idx] * dmask[nc] : 0.0f;
+        const float mb = dbeta[c] * invM, mg = dgamma[c] * invM;
+        const size_t eo[4] = {e0, e0 + 1, e0 + WI, e0 + WI + 1};
+#pragma unroll
+        for (int i = 0; i < 4; i++) dx[eo[i]] = g * rs * ((i == k ? dyk : 0.0f) - mb - xh[i] * mg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head
+// spatial attention + global average pool: a[n][p] = sigmoid(ba + sum_c wa[c] h[n][c][p]); g[n][c] = mean_p h a
+__global__ __launch_bounds__(256) void lgt_att_fwd_kernel(const float* __restrict__ h, const float* __restrict__ wa,
+                                                          const float* __restrict__ ba, int spatial, int F, int P,
+                                                          float* __restrict__ a, float* __restrict__ g) {
+    __shared__ float s_a[64];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* hn = h + (size_t)n * F * P;
+    if (t < P) {
+        float v = 1.0f;
+        if (spatial) {
+            float s = ba[0];
+            for (int c = 0; c < F; c++) s += wa[c] * hn[c * P + t];
+            v = 1.0f / (1.0f + expf(-s));
+        }
+        s_a[t] = v;
+        a[(size_t)n * P + t] = v;
+    }
+    __syncthreads();
+    for (int c = t; c < F; c += 256) {
+        float s = 0.0f;
+        for (int p = 0; p < P; p++) s += hn[c * P + p] * s_a[p];
+        g[(size_t)n * F + c] = s / (float)P;
+    }
+}
+
+// dh[n][c][p] = dg[n][c] a[p] / P + ds[p] wa[c],  ds[p] = a (1-a) sum_c dg[c] h[c][p] / P;
+// part[n][c] = sum_p ds[p] h[c][p] (-> d wa),  part[n][F] = sum_p ds[p] (-> d ba)
+__global__ __launch_bounds__(256) void lgt_att_bwd_kernel(const float* __restrict__ h, const float* __restrict__ a,
+                                                          const float* __restrict__ dg, const float* __restrict__ wa,
+                                                          int spatial, int F, int P, float* __restrict__ dh,
+                                                          float* __restrict__ part) {
+    __shared__ float s_a[64], s_ds[64];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* hn = h + (size_t)n * F * P;
+    const float* dgn = dg + (size_t)n * F;
+    if (t < P) {
+        const float av = a[(size_t)n * P + t];
+        float ds = 0.0f;
+        if (spatial) {
+            float s = 0.0f;
+            for (int c = 0; c < F; c++) s += dgn[c] * hn[c * P + t];
+            ds = s / (float)P * av * (1.0f - av);
+        }
+        s_a[t] = av;
+        s_ds[t] = ds;
+    }
+    __syncthreads();
+    for (int c = t; c < F; c += 256) {
+        const float d = dgn[c] / (float)P, w = spatial ? wa[c] : 0.0f;
+        float pw = 0.0f;
+        for (int p = 0; p < P; p++) {
+            dh[((size_t)n * F + c) * P + p] = d * s_a[p] + s_ds[p] * w;
+            pw += s_ds[p] * hn[c * P + p];
+        }
+        if (spatial) part[(size_t)n * (F + 1) + c] = pw;
+    }
+    if (spatial && t == 0) {
+        float s = 0.0f;
+        for (int p = 0; p < P; p++) s += s_ds[p];
+        part[(size_t)n * (F + 1) + F] = s;
+    }
+}
+
+__global__ void lgt_colsum_kernel(const float* __restrict__ part, int N, int K, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.0f;
+    for (int n = 0; n < N; n++) s += part[(size_t)n * K + k];
+    out[k] = s;
+}
+
+// Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples)
+__global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ Y, int N, int I,
+                                                         int O) {
+    const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= O) return;
+    for (int n = blockIdx.y * 16; n < min(N, (int)blockIdx.y * 16 + 16); n++) {
+        float s = 0.0f;
+        for (int i = lane; i < I; i += 64) s += X[(size_t)n * I + i] * W[(size_t)o * I + i];
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
+        if (lane == 0) Y[(size_t)n * O + o] = s + b[o];
+    }
+}
+
+// BatchNorm1d (batch statistics) + ReLU + Dropout keep mask; one thread per feature
+__global__ void lgt_bn1d_fwd_kernel(const float* __restrict__ U, const float* __restrict__ gam,
+                                    const float* __restrict__ bet, const float* __restrict__ mask, float* __restrict__ Y,
+                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                    float* __restrict__ run_var, int N, int O, float eps, float momentum) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    float s = 0.0f;
+    for (int n = 0; n < N; n++) s += U[(size_t)n * O + o];
+    const float mu = s / (float)N;
+    float v = 0.0f;
+    for (int n = 0; n < N; n++) {
+        const float d = U[(size_t)n * O + o] - mu;
+        v += d * d;
+    }
+    const float var = v / (float)N, rs = 1.0f / sqrtf(var + eps);
+    mean[o] = mu;
+    rstd[o] = rs;
+    run_mean[o] = (1.0f - momentum) * run_mean[o] + momentum * mu;
+    run_var[o] = (1.0f - momentum) * run_var[o] + momentum * var * ((float)N / (float)(N > 1 ? N - 1 : 1));
+    const float g = gam[o], b = bet[o];
+    for (int n = 0; n < N; n++)
+        Y[(size_t)n * O + o] = fmaxf((U[(size_t)n * O + o] - mu) * rs * g + b, 0.0f) * mask[(size_t)n * O + o];
+}
+
+__global__ void lgt_bn1d_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ U,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gam, const float* __restrict__ bet,
+                                    const float* __restrict__ mask, float* __restrict__ dU, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int N, int O) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    const float mu = mean[o], rs = rstd[o], g = gam[o], b = bet[o];
+    float sg = 0.0f, sb = 0.0f;
+    for (int n = 0; n < N; n++) {
+        const float xh = (U[(size_t)n * O + o] - mu) * rs;
+        const float dy = (xh * g + b > 0.0f) ? dY[(size_t)n * O + o] * mask[(size_t)n * O + o] : 0.0f;
+        sg += dy * xh;
+        sb += dy;
+    }
+    dgamma[o] = sg;
+    dbeta[o] = sb;
+    const float invN = 1.0f / (float)N;
+    for (int n = 0; n < N; n++) {
+        const float xh = (U[(size_t)n * O + o] - mu) * rs;
+        const float dy = (xh * g + b > 0.0f) ? dY[(size_t)n * O + o] * mask[(size_t)n * O + o] : 0.0f;
+        dU[(size_t)n * O + o] = g * rs * (dy - sb * invN - xh * sg * invN);
+    }
+}
+
+// dX[n][i] = sum_o dY[n][o] W[o][i]
+__global__ void lgt_fc_bwd_x_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
+                                    int N, int I, int O) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (i >= I) return;
+    float s = 0.0f;
+    for (int o = 0; o < O; o++) s += dY[(size_t)n * O + o] * W[(size_t)o * I + i];
+    dX[(size_t)n * I + i] = s;
+}
+
+// dW[o][i] = sum_n dY[n][o] X[n][i], db[o] = sum_n dY[n][o]
+__global__ void lgt_fc_bwd_w_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dW,
+                                    float* __restrict__ db, int N, int I, int O) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+    if (i >= I) return;
+    float s = 0.0f, sb = 0.0f;
+    for (int n = 0; n < N; n++) {
+        const float d = dY[(size_t)n * O + o];
+        s += d * X[(size_t)n * I + i];
+        sb += d;
+    }
+    dW[(size_t)o * I + i] = s;
+    if (i == 0) db[o] = sb;
+}
+
+// BCEWithLogitsLoss(pos_weight), mean over the batch (train_model.py:221,251): loss and d loss / d logit
+__global__ __launch_bounds__(256) void lgt_loss_kernel(const float* __restrict__ z, const float* __restrict__ y, int N,
+                                                       float pos_weight, float* __restrict__ loss, float* __restrict__ dz) {
+    __shared__ float s_red[4];
+    float s = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float zn = z[n], yn = y[n];
+        // softplus(-z) = max(-z, 0) + log1p(exp(-|z|))
+        const float sp_neg = fmaxf(-zn, 0.0f) + log1pf(expf(-fabsf(zn)));
+        const float lw = 1.0f + (pos_weight - 1.0f) * yn;
+        s += (1.0f - yn) * zn + lw * sp_neg;
+        const float sig = 1.0f / (1.0f + expf(-zn));
+        dz[n] = ((1.0f - yn) - lw * (1.0f - sig)) / (float)N;
+    }
+    s = block_sum(s, s_red);
+    if (threadIdx.x == 0) loss[0] = s / (float)N;
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(256) void lgt_sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+    __shared__ float s_red[4];
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+    s = block_sum(s, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+struct AdamHp { float lr, beta1, beta2, eps, weight_decay, max_norm; };
+
+// clip_grad_norm_(max_norm) + torch.optim.Adam(weight_decay = L2 added to the gradient); state[0] = step count (float),
+// state[1] = total gradient norm of this step (before clipping)
+__global__ __launch_bounds__(256) void lgt_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                       const float* __restrict__ partial, int nparts,
+                                                       const AdamHp* __restrict__ hp_, float* __restrict__ state) {
+    const AdamHp hp = *hp_;
+    float ss = 0.0f;
+    for (int k = 0; k < nparts; k++) ss += partial[k];
+    const float norm = sqrtf(ss);
+    float coef = hp.max_norm > 0.0f ? fminf(hp.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    const float step = state[0] + 1.0f;
+    const float bc1 = 1.0f - powf(hp.beta1, step), bc2 = 1.0f - powf(hp.beta2, step);
+    const float step_size = hp.lr / bc1, bc2s = sqrtf(bc2);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float gi = g[i] * coef + hp.weight_decay * p[i];
+        const float mi = hp.beta1 * m[i] + (1.0f - hp.beta1) * gi;
+        const float vi = hp.beta2 * v[i] + (1.0f - hp.beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + hp.eps));
+    }
+    if (i == 0) state[2] = norm;
+}
+__global__ void lgt_step_kernel(float* state) { state[0] += 1.0f; state[1] = state[2]; }
+
+// keep mask of a dropout layer: 0 or 1/(1-p); counter-based hash of (seed, index)
+__global__ void lgt_mask_kernel(float* __restrict__ mask, size_t n, float p, uint64_t seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t zz = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+    zz ^= zz >> 31;
+    const float u = (float)(zz >> 40) * (1.0f / 16777216.0f);
+    mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+}  // namespace
+
+// ================================================================================================= host side
+struct TrainLayer {
+    int ci = 0, co = 0, wi = 0;
+    bool pool = false;
+    size_t w = 0, b = 0, g = 0, be = 0;   // offsets into the flat parameter vector
+    size_t rm = 0, rv = 0;                // offsets into the flat buffer vector (running mean / var)
+    size_t st = 0;                        // offset into the saved mean / rstd vector
+    float *x = nullptr, *out = nullptr;   // conv output (pre-BN), layer output (post BN/ReLU[/pool/dropout])
+    float *wpf = nullptr, *wpd = nullptr;
+    size_t mask = 0;                      // offset of the block's Dropout2d mask inside one sample's mask row (pool layers)
+};
+struct TrainFc { int in = 0, out = 0; size_t w = 0, b = 0, g = 0, be = 0, rm = 0, rv = 0, st = 0, mask = 0; float *u = nullptr, *y = nullptr; };
+
+struct lg_trainer {
+    int device = 0, n_blocks = 3, att = LG_ATT_SPATIAL, capN = 0, F = 256, P = 16;
+    int filters[4] = {64, 128, 256, 0};
+    std::vector<TrainLayer> layers;
+    TrainFc fc[4];
+    size_t att_w = 0, att_b = 0;
+    size_t n_params = 0, n_buffers = 0, n_stats = 0, mask_row = 0;
+    float drop2d_p = 0.3f, drop_p[3] = {0.5f, 0.5f, 0.4f};
+    size_t mask_fc[3] = {0, 0, 0};
+    float *P_ = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *B = nullptr, *mean = nullptr, *rstd = nullptr;
+    float *xin = nullptr, *labels = nullptr, *masks = nullptr;
+    float *dA[2] = {nullptr, nullptr}, *dX = nullptr, *partial = nullptr;
+    size_t partial_floats = 0;
+    float *att_a = nullptr, *gap = nullptr, *att_part = nullptr, *dfc[2] = {nullptr, nullptr}, *logits = nullptr, *dz = nullptr;
+    float *loss = nullptr, *state = nullptr, *norm_part = nullptr;
+    AdamHp* hp = nullptr;
+    hipStream_t stream = nullptr;
+    int64_t steps = 0;
+    std::string err;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+constexpr int kNormParts = 256;
+constexpr int kMaxSplit = 128;
+
+#define TR_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            tr->err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+            return LG_ERR_HIP;                                                                           \
+        }                                                                                                \
+    } while (0)
+
+int dalloc(lg_trainer* tr, float** p, size_t floats) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(floats, 1) * sizeof(float)) != hipSuccess) {
+        tr->err = "hipMalloc failed";
+        return LG_ERR_NOMEM;
+    }
+    tr->allocs.push_back(q);
+    *p = (float*)q;
+    return LG_OK;
+}
+
+void launch_conv(int wi, dim3 grid, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N,
+                 int CI, int CO) {
+    switch (wi) {
+        case 32: hipLaunchKernelGGL(lgt_conv_kernel<32>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
+        case 16: hipLaunchKernelGGL(lgt_conv_kernel<16>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
+        case 8: hipLaunchKernelGGL(lgt_conv_kernel<8>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
+        default: hipLaunchKernelGGL(lgt_conv_kernel<4>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
+    }
+}
+void launch_wgrad(int wi, dim3 grid, hipStream_t s, const float* a, const float* dx, float* partial, int N, int CI, int CO,
+                  int ntiles) {
+    switch (wi) {
+        case 32: hipLaunchKernelGGL(lgt_wgrad_kernel<32>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        case 16: hipLaunchKernelGGL(lgt_wgrad_kernel<16>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        case 8: hipLaunchKernelGGL(lgt_wgrad_kernel<8>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        default: hipLaunchKernelGGL(lgt_wgrad_kernel<4>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+    }
+}
+int conv_tiles(int wi, int N, int tile) {   // pixel tiles of `tile` pixels covering N samples
+    const int hw = wi * wi;
+    return hw >= tile ? N * (hw / tile) : (N + tile / hw - 1) / (tile / hw);
+}
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" {
+
+int lg_train_create(int device, int n_blocks, const int32_t* filters, int attention_type, int max_batch, lg_trainer** out) {
+    if (!out) return LG_ERR_INVALID;
+    *out = nullptr;
+    if (!filters || n_blocks < 1 || n_blocks > 4 || max_batch < 2 || max_batch > 8192) return LG_ERR_INVALID;
+    if (attention_type != LG_ATT_SPATIAL && attention_type != LG_ATT_NONE) return LG_ERR_UNSUPPORTED;
+    for (int b = 0; b < n_blocks; b++)
+        if (filters[b] < 32 || filters[b] % 32 != 0 || filters[b] > 1024) return LG_ERR_INVALID;
+    if (filters[n_blocks - 1] % 4 != 0) return LG_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return LG_ERR_HIP;
+    lg_trainer* tr = new (std::nothrow) lg_trainer;
+    if (!tr) return LG_ERR_NOMEM;
+    tr->device = device;
+    tr->n_blocks = n_blocks;
+    tr->att = attention_type;
+    tr->capN = max_batch;
+    hipSetDevice(device);
+
+    // parameter order = model.parameters() of the reference module (model.py:12-85)
+    size_t po = 0, bo = 0, so = 0, mo = 0;
+    int c = 9, wi = 32;
+    for (int b = 0; b < n_blocks; b++) {
+        tr->filters[b] = filters[b];
+        for (int k = 0; k < 2; k++) {
+            TrainLayer L;
+            L.ci = k == 0 ? c : filters[b];
+            L.co = filters[b];
+            L.wi = wi;
+            L.pool = k == 1;
+            L.w = po; po += (size_t)L.co * L.ci * 9;
+            L.b = po; po += L.co;
+            L.g = po; po += L.co;
+            L.be = po; po += L.co;
+            L.rm = bo; bo += L.co;
+            L.rv = bo; bo += L.co;
+            L.st = so; so += L.co;
+            if (L.pool) { L.mask = mo; mo += L.co; }
+            tr->layers.push_back(L);
+        }
+        c = filters[b];
+        wi /= 2;
+    }
+    const int F = c;
+    tr->F = F;
+    tr->P = wi * wi;
+    if (attention_type == LG_ATT_SPATIAL) {
+        tr->att_w = po; po += F;
+        tr->att_b = po; po += 1;
+    }
+    const int fin[4] = {F, F, F / 2, F / 4}, fout[4] = {F, F / 2, F / 4, 1};
+    for (int k = 0; k < 4; k++) {
+        TrainFc& f = tr->fc[k];
+        f.in = fin[k];
+        f.out = fout[k];
+        f.w = po; po += (size_t)f.in * f.out;
+        f.b = po; po += f.out;
+        if (k < 3) {
+            f.g = po; po += f.out;
+            f.be = po; po += f.out;
+            f.rm = bo; bo += f.out;
+            f.rv = bo; bo += f.out;
+            f.st = so; so += f.out;
+            f.mask = mo; mo += f.out;
+        }
+    }
+    tr->n_params = po;
+    tr->n_buffers = bo;
+    tr->n_stats = so;
+    tr->mask_row = mo;
+
+    const size_t N = (size_t)max_batch;
+    int rc = LG_OK;
+    auto A = [&](float** p, size_t n) { if (rc == LG_OK) rc = dalloc(tr, p, n); };
+    A(&tr->P_, po); A(&tr->G, po); A(&tr->M, po); A(&tr->V, po); A(&tr->B, bo); A(&tr->mean, so); A(&tr->rstd, so);
+    A(&tr->xin, N * 9 * 1024); A(&tr->labels, N); A(&tr->masks, N * mo);
+    size_t max_act = 0;
+    for (auto& L : tr->layers) {
+        const size_t full = N * L.co * L.wi * L.wi;
+        A(&L.x, full);
+        A(&L.out, L.pool ? full / 4 : full);
+        A(&L.wpf, (size_t)9 * L.ci * L.co);
+        A(&L.wpd, (size_t)9 * L.ci * L.co);
+        max_act = std::max(max_act, std::max(full, N * L.ci * L.wi * L.wi));
+        const int tiles = std::min(conv_tiles(L.wi, max_batch, 128), kMaxSplit);
+        tr->partial_floats = std::max(tr->partial_floats, (size_t)tiles * 9 * L.ci * L.co);
+    }
+    A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX, max_act); A(&tr->partial, tr->partial_floats);
+    A(&tr->att_a, N * tr->P); A(&tr->gap, N * F); A(&tr->att_part, N * (F + 1));
+    A(&tr->dfc[0], N * F); A(&tr->dfc[1], N * F); A(&tr->logits, N); A(&tr->dz, N);
+    for (int k = 0; k < 4; k++) { A(&tr->fc[k].u, N * tr->fc[k].out); if (k < 3) A(&tr->fc[k].y, N * tr->fc[k].out); }
+    A(&tr->loss, 4); A(&tr->state, 4); A(&tr->norm_part, kNormParts);
+    float* hp = nullptr;
+    A(&hp, sizeof(AdamHp) / sizeof(float));
+    tr->hp = (AdamHp*)hp;
+    if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
+    if (rc != LG_OK) {
+        for (void* q : tr->allocs) hipFree(q);
+        delete tr;
+        return rc;
+    }
+    hipMemset(tr->P_, 0, po * 4); hipMemset(tr->G, 0, po * 4); hipMemset(tr->M, 0, po * 4); hipMemset(tr->V, 0, po * 4);
+    hipMemset(tr->B, 0, bo * 4); hipMemset(tr->state, 0, 16); hipMemset(tr->loss, 0, 16);
+    hipDeviceSynchronize();
+    *out = tr;
+    return LG_OK;
+}
+
+int lg_train_destroy(lg_trainer* tr) {
+    if (!tr) return LG_ERR_INVALID;
+    hipSetDevice(tr->device);
+    hipDeviceSynchronize();
+    if (tr->stream) hipStreamDestroy(tr->stream);
+    for (void* q : tr->allocs) hipFree(q);
+    delete tr;
+    return LG_OK;
+}
+
+const char* lg_train_last_error(lg_trainer* tr) { return tr ? tr->err.c_str() : "null trainer"; }
+
+int lg_train_sizes(lg_trainer* tr, int64_t* n_params, int64_t* n_buffers, int64_t* mask_row) {
+    if (!tr) return LG_ERR_INVALID;
+    if (n_params) *n_params = (int64_t)tr->n_params;
+    if (n_buffers) *n_buffers = (int64_t)tr->n_buffers;
+    if (mask_row) *mask_row = (int64_t)tr->mask_row;
+    return LG_OK;
+}
+
+int lg_train_set_state(lg_trainer* tr, const float* params, const float* buffers, const float* exp_avg,
+                       const float* exp_avg_sq, int64_t step) {
+    if (!tr || !params || !buffers || step < 0) return LG_ERR_INVALID;
+    hipSetDevice(tr->device);
+    TR_HIP(hipStreamSynchronize(tr->stream));
+    TR_HIP(hipMemcpy(tr->P_, params, tr->n_params * 4, hipMemcpyHostToDevice));
+    TR_HIP(hipMemcpy(tr->B, buffers, tr->n_buffers * 4, hipMemcpyHostToDevice));
+    if (exp_avg) TR_HIP(hipMemcpy(tr->M, exp_avg, tr->n_params * 4, hipMemcpyHostToDevice));
+    else TR_HIP(hipMemset(tr->M, 0, tr->n_params * 4));
+    if (exp_avg_sq) TR_HIP(hipMemcpy(tr->V, exp_avg_sq, tr->n_params * 4, hipMemcpyHostToDevice));
+    else TR_HIP(hipMemset(tr->V, 0, tr->n_params * 4));
+    const float st[4] = {(float)step, 0.f, 0.f, 0.f};
+    TR_HIP(hipMemcpy(tr->state, st, 16, hipMemcpyHostToDevice));
+    tr->steps = step;
+    return LG_OK;
+}
+
+int lg_train_get_state(lg_trainer* tr, float* params, float* buffers, float* exp_avg, float* exp_avg_sq, float* grads,
+                       int64_t* step) {
+    if (!tr) return LG_ERR_INVALID;
+    hipSetDevice(tr->device);
+    TR_HIP(hipStreamSynchronize(tr->stream));
+    if (params) TR_HIP(hipMemcpy(params, tr->P_, tr->n_params * 4, hipMemcpyDeviceToHost));
+    if (buffers) TR_HIP(hipMemcpy(buffers, tr->B, tr->n_buffers * 4, hipMemcpyDeviceToHost));
+    if (exp_avg) TR_HIP(hipMemcpy(exp_avg, tr->M, tr->n_params * 4, hipMemcpyDeviceToHost));
+    if (exp_avg_sq) TR_HIP(hipMemcpy(exp_avg_sq, tr->V, tr->n_params * 4, hipMemcpyDeviceToHost));
+    if (grads) TR_HIP(hipMemcpy(grads, tr->G, tr->n_params * 4, hipMemcpyDeviceToHost));
+    if (step) *step = tr->steps;
+    return LG_OK;
+}
+
+// One optimisation step on N samples.  x [N][9][32][32], labels [N] (0/1) and masks (NULL, or [N][mask_row] keep masks
+// already scaled by 1/(1-p)) are DEVICE pointers; hp is a host struct.  apply_update = 0 computes loss and gradients only.
+int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, const float* masks, uint64_t seed,
+                  const lg_train_hparams* hp, int apply_update, float* loss_host, float* grad_norm_host,
+                  float* logits_dev) {
+    if (!tr || !x || !labels || !hp) return LG_ERR_INVALID;
+    if (N < 2 || N > tr->capN) { tr->err = "lg_train_step: N must be in [2, max_batch] (BatchNorm needs a batch)"; return LG_ERR_INVALID; }
+    hipSetDevice(tr->device);
+    hipStream_t s = tr->stream;
+    const int F = tr->F, P = tr->P;
+    const float eps = 1e-5f, mom = 0.1f;
+    TR_HIP(hipMemcpyAsync(tr->xin, x, (size_t)N * 9 * 1024 * 4, hipMemcpyDeviceToDevice, s));
+    TR_HIP(hipMemcpyAsync(tr->labels, labels, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    const AdamHp h = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->max_grad_norm};
+    TR_HIP(hipMemcpyAsync(tr->hp, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    const size_t mrow = tr->mask_row;
+    // masks are stored layer-major: layer block [N][width] at offset N * (row offset of the layer)
+    if (masks) {
+        TR_HIP(hipMemcpyAsync(tr->masks, masks, (size_t)N * mrow * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        for (auto& L : tr->layers)
+            if (L.pool) {
+                const size_t n = (size_t)N * L.co;
+                hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tr->masks + (size_t)N * L.mask, n,
+                                   tr->drop2d_p, seed * 0x100000001B3ull + L.mask + 0x51ull * (uint64_t)tr->steps);
+            }
+        for (int k = 0; k < 3; k++) {
+            const size_t n = (size_t)N * tr->fc[k].out;
+            hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tr->masks + (size_t)N * tr->fc[k].mask, n,
+                               tr->drop_p[k], seed * 0x100000001B3ull + tr->fc[k].mask + 0x51ull * (uint64_t)tr->steps);
+        }
+    }
+    TR_HIP(hipMemsetAsync(tr->G, 0, tr->n_params * 4, s));   // conv / pre-BN linear biases: exact zero gradient (see DESIGN)
+
+    // ---------------- forward
+    const float* a = tr->xin;
+    for (auto& L : tr->layers) {
+        const size_t nw = (size_t)9 * L.ci * L.co;
+        hipLaunchKernelGGL(lgt_pack_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, tr->P_ + L.w, L.ci, L.co, L.wpf, L.wpd);
+        launch_conv(L.wi, dim3(conv_tiles(L.wi, N, 256), cdiv(L.co, 64)), s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
+        hipLaunchKernelGGL(lgt_bn_stats_kernel, dim3(L.co), dim3(256), 0, s, L.x, N, L.co, L.wi * L.wi, eps, mom,
+                           tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
+        if (L.pool) {
+            const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
+            hipLaunchKernelGGL(lgt_bn_act_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->mean + L.st,
+                               tr->rstd + L.st, tr->P_ + L.g, tr->P_ + L.be, tr->masks + (size_t)N * L.mask, L.out, N, L.co, L.wi);
+        } else {
+            const size_t n = (size_t)N * L.co * L.wi * L.wi;
+            hipLaunchKernelGGL(lgt_bn_act_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->mean + L.st,
+                               tr->rstd + L.st, tr->P_ + L.g, tr->P_ + L.be, (const float*)nullptr, L.out, N, L.co, L.wi);
+        }
+        a = L.out;
+    }
+    const int spatial = tr->att == LG_ATT_SPATIAL;
+    hipLaunchKernelGGL(lgt_att_fwd_kernel, dim3(N), dim3(256), 0, s, a, tr->P_ + tr->att_w, tr->P_ + tr->att_b, spatial, F, P,
+                       tr->att_a, tr->gap);
+    const float* fin = tr->gap;
+    for (int k = 0; k < 4; k++) {
+        TrainFc& f = tr->fc[k];
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(f.out, 4), cdiv(N, 16)), dim3(256), 0, s, fin, tr->P_ + f.w,
+                           tr->P_ + f.b, k < 3 ? f.u : tr->logits, N, f.in, f.out);
+        if (k < 3) {
+            hipLaunchKernelGGL(lgt_bn1d_fwd_kernel, dim3(cdiv(f.out, 64)), dim3(64), 0, s, f.u, tr->P_ + f.g, tr->P_ + f.be,
+                               tr->masks + (size_t)N * f.mask, f.y, tr->mean + f.st, tr->rstd + f.st, tr->B + f.rm,
+                               tr->B + f.rv, N, f.out, eps, mom);
+            fin = f.y;
+        }
+    }
+    hipLaunchKernelGGL(lgt_loss_kernel, dim3(1), dim3(256), 0, s, tr->logits, tr->labels, N, hp->pos_weight, tr->loss, tr->dz);
+
+    // ---------------- backward: classifier
+    const float* dy = tr->dz;
+    for (int k = 3; k >= 0; k--) {
+        TrainFc& f = tr->fc[k];
+        const float* xin_k = k == 0 ? tr->gap : tr->fc[k - 1].y;
+        hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(f.in, 64), f.out), dim3(64), 0, s, dy, xin_k, tr->G + f.w,
+                           tr->G + f.b, N, f.in, f.out);
+        float* dxk = tr->dfc[0];   // never the buffer dy lives in (dz or dfc[1]): the kernel reads all of dy per output
+        hipLaunchKernelGGL(lgt_fc_bwd_x_kernel, dim3(cdiv(f.in, 64), N), dim3(64), 0, s, dy, tr->P_ + f.w, dxk, N, f.in, f.out);
+        if (k > 0) {
+            TrainFc& p = tr->fc[k - 1];   // dxk = gradient at p.y -> through dropout / ReLU / BN1d to p.u
+            float* du = tr->dfc[1];
+            hipLaunchKernelGGL(lgt_bn1d_bwd_kernel, dim3(cdiv(p.out, 64)), dim3(64), 0, s, dxk, p.u, tr->mean + p.st,
+                               tr->rstd + p.st, tr->P_ + p.g, tr->P_ + p.be, tr->masks + (size_t)N * p.mask, du, tr->G + p.g,
+                               tr->G + p.be, N, p.out);
+            dy = du;
+        } else {
+            dy = dxk;   // gradient at the pooled features [N][F]
+        }
+    }
+    // attention + average pool
+    const TrainLayer& last = tr->layers.back();
+    hipLaunchKernelGGL(lgt_att_bwd_kernel, dim3(N), dim3(256), 0, s, last.out, tr->att_a, dy, tr->P_ + tr->att_w, spatial, F, P,
+                       tr->dA[0], tr->att_part);
+    if (spatial)
+        hipLaunchKernelGGL(lgt_colsum_kernel, dim3(cdiv(F + 1, 64)), dim3(64), 0, s, tr->att_part, N, F + 1, tr->G + tr->att_w);
+    // encoder
+    int cur = 0;
+    for (int li = (int)tr->layers.size() - 1; li >= 0; li--) {
+        TrainLayer& L = tr->layers[li];
+        const float* ain = li == 0 ? tr->xin : tr->layers[li - 1].out;
+        const float* dm = L.pool ? tr->masks + (size_t)N * L.mask : nullptr;
+        const float *mu = tr->mean + L.st, *rs = tr->rstd + L.st, *g = tr->P_ + L.g, *be = tr->P_ + L.be;
+        if (L.pool) {
+            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, N, L.co, L.wi);
+            const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
+            hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, tr->dX, N, L.co, L.wi);
+        } else {
+            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<false>, dim3(L.co), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, N, L.co, L.wi);
+            const size_t n = (size_t)N * L.co * L.wi * L.wi;
+            hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, tr->dX, N, L.co, L.wi);
+        }
+        const int ntiles = conv_tiles(L.wi, N, 128), S = std::min(ntiles, kMaxSplit);
+        launch_wgrad(L.wi, dim3(S, cdiv(L.co, 64), cdiv(L.ci, 64)), s, ain, tr->dX, tr->partial, N, L.ci, L.co, ntiles);
+        const size_t nw = (size_t)9 * L.ci * L.co;
+        hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, tr->partial, S, L.ci, L.co, tr->G + L.w);
+        if (li > 0) {   // backward-data: a convolution of dX with the mirrored, channel-swapped weights
+            launch_conv(L.wi, dim3(conv_tiles(L.wi, N, 256), cdiv(L.ci, 64)), s, tr->dX, L.wpd, (const float*)nullptr,
+                        tr->dA[cur ^ 1], N, L.co, L.ci);
+            cur ^= 1;
+        }
+    }
+    // ---------------- optimizer
+    hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
+    if (apply_update) {
+        hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
+                           tr->n_params, tr->norm_part, kNormParts, tr->hp, tr->state);
+        hipLaunchKernelGGL(lgt_step_kernel, dim3(1), dim3(1), 0, s, tr->state);
+        tr->steps++;
+    }
+    if (logits_dev) TR_HIP(hipMemcpyAsync(logits_dev, tr->logits, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    TR_HIP(hipGetLastError());
+    if (loss_host || grad_norm_host) {
+        float l = 0.f;
+        TR_HIP(hipMemcpyAsync(&l, tr->loss, 4, hipMemcpyDeviceToHost, s));
+        float parts[kNormParts];
+        TR_HIP(hipMemcpyAsync(parts, tr->norm_part, sizeof(parts), hipMemcpyDeviceToHost, s));
+        TR_HIP(hipStreamSynchronize(s));
+        if (loss_host) *loss_host = l;
+        if (grad_norm_host) {
+            float ss = 0.f;
+            for (int k = 0; k < kNormParts; k++) ss += parts[k];
+            *grad_norm_host = sqrtf(ss);
+        }
+    }
+    return LG_OK;
+}
+
+int lg_train_sync(lg_trainer* tr) {
+    if (!tr) return LG_ERR_INVALID;
+    hipSetDevice(tr->device);
+    TR_HIP(hipStreamSynchronize(tr->stream));
+    return LG_OK;
+}
+
+}  // extern "C"

@@ -534,6 +534,87 @@ def cnn_forward(params, x, dtype=None):
     return h.reshape(-1).to(torch.float64).numpy()
 
 
+def cnn_train_step(params, x, y, masks=None, opt_state=None, lr=0.0005, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+                   max_grad_norm=1.0, pos_weight=2.0, apply_update=True, dtype=None):
+    """One iteration of scripts/train_model.py:247-265 restated with torch (CPU, fp32) functional ops + autograd:
+    GraspPointCNN.forward in TRAIN mode (model.py:101-128: batch-statistics BatchNorm with momentum 0.1, Dropout2d(0.3)
+    after every encoder block, Dropout(0.5/0.5/0.4) in the classifier), BCEWithLogitsLoss(pos_weight) (:221,251),
+    clip_grad_norm_(max_norm) (:256), Adam(lr, weight_decay as L2) (:222,258).
+    params: module state dict (numpy / torch; spatial attention or none).  masks: list of [N, width] keep masks already
+    scaled by 1/(1-p), one per dropout layer in module order (None = no dropout: every mask 1).
+    opt_state: {'exp_avg': {k: arr}, 'exp_avg_sq': {...}, 'step': int} or None (fresh optimizer).
+    Returns dict(loss, logits, grad_norm, grads, params (updated state dict incl. running statistics), opt_state)."""
+    import torch
+    import torch.nn.functional as F
+
+    dt = dtype or torch.float32   # float64: the conditioning reference of the tests
+    p = {k: torch.as_tensor(np.asarray(v)).to(dt).clone() for k, v in params.items()
+         if not k.endswith("num_batches_tracked")}
+    names = [k for k in p if "running_" not in k]
+    for k in names:
+        p[k].requires_grad_(True)
+    h = torch.as_tensor(np.asarray(x)).to(dt)
+    yt = torch.as_tensor(np.asarray(y)).to(dt)
+    n_blocks = 0
+    while f"encoder.{n_blocks}.0.weight" in p:
+        n_blocks += 1
+    mi = 0
+
+    def mask(width):
+        nonlocal mi
+        mk = None if masks is None else torch.as_tensor(np.asarray(masks[mi])).to(dt)
+        mi += 1
+        assert mk is None or tuple(mk.shape) == (h.shape[0], width)
+        return mk
+
+    for b in range(n_blocks):
+        for conv, bn in ((0, 1), (3, 4)):
+            h = F.conv2d(h, p[f"encoder.{b}.{conv}.weight"], p[f"encoder.{b}.{conv}.bias"], padding=1)
+            h = F.batch_norm(h, p[f"encoder.{b}.{bn}.running_mean"], p[f"encoder.{b}.{bn}.running_var"],
+                             p[f"encoder.{b}.{bn}.weight"], p[f"encoder.{b}.{bn}.bias"], True, 0.1, 1e-5)
+            h = F.relu(h)
+        h = F.max_pool2d(h, 2)
+        mk = mask(h.shape[1])                       # Dropout2d: one Bernoulli draw per (sample, channel)
+        if mk is not None:
+            h = h * mk[:, :, None, None]
+    if "attention.0.weight" in p:
+        h = h * torch.sigmoid(F.conv2d(h, p["attention.0.weight"], p["attention.0.bias"]))
+    h = h.mean(dim=(2, 3))
+    for idx in (0, 4, 8):
+        h = F.linear(h, p[f"classifier.{idx}.weight"], p[f"classifier.{idx}.bias"])
+        h = F.batch_norm(h, p[f"classifier.{idx + 1}.running_mean"], p[f"classifier.{idx + 1}.running_var"],
+                         p[f"classifier.{idx + 1}.weight"], p[f"classifier.{idx + 1}.bias"], True, 0.1, 1e-5)
+        h = F.relu(h)
+        mk = mask(h.shape[1])
+        if mk is not None:
+            h = h * mk
+    logits = F.linear(h, p["classifier.12.weight"], p["classifier.12.bias"]).reshape(-1)
+    loss = F.binary_cross_entropy_with_logits(logits, yt, pos_weight=torch.tensor([float(pos_weight)], dtype=dt))
+    grads = torch.autograd.grad(loss, [p[k] for k in names])
+    grads = {k: g.detach() for k, g in zip(names, grads)}
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).to(dt)
+    coef = min(float(max_grad_norm) / (float(total) + 1e-6), 1.0) if max_grad_norm and max_grad_norm > 0 else 1.0
+    st = opt_state or {"exp_avg": {}, "exp_avg_sq": {}, "step": 0}
+    step = int(st["step"]) + (1 if apply_update else 0)
+    new_p = {k: v.detach().clone() for k, v in p.items()}
+    new_m, new_v = {}, {}
+    if apply_update:
+        b1, b2 = betas
+        bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+        for k in names:
+            g = grads[k] * coef + weight_decay * new_p[k]
+            m = torch.as_tensor(np.asarray(st["exp_avg"].get(k, np.zeros(g.shape, np.float32)))).to(dt)
+            v = torch.as_tensor(np.asarray(st["exp_avg_sq"].get(k, np.zeros(g.shape, np.float32)))).to(dt)
+            m = b1 * m + (1.0 - b1) * g
+            v = b2 * v + (1.0 - b2) * g * g
+            new_p[k] = new_p[k] - (lr / bc1) * (m / (v.sqrt() / math.sqrt(bc2) + eps))
+            new_m[k], new_v[k] = m, v
+    return {"loss": float(loss.detach()), "logits": logits.detach().numpy().astype(np.float64), "grad_norm": float(total),
+            "grads": {k: g.numpy() for k, g in grads.items()}, "params": {k: v.numpy() for k, v in new_p.items()},
+            "opt_state": {"exp_avg": {k: v.numpy() for k, v in new_m.items()},
+                          "exp_avg_sq": {k: v.numpy() for k, v in new_v.items()}, "step": step}}
+
+
 # --------------------------------------------------------------------------- leaf_scorer.py
 def visibility_score(leaf_mask):
     """OptimalLeafSelector._calculate_visibility_score (scripts/utils/leaf_scorer.py:277-306)."""
