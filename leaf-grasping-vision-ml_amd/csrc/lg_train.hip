@@ -54,29 +54,36 @@ __device__ inline float block_sum(float v, float* s_red) {   // 256 threads; res
 
 // ------------------------------------------------------------------------------------------------ conv fwd / dgrad
 // out[n][co][y][x] = bias[co] + sum_{tap,ci} wp[tap][ci][co] * in[n][ci][y+ky-1][x+kx-1]     (zero padding)
-// Workgroup: 256 pixels x 64 output channels; wave: 64 pixels x 64 channels (2 x 2 accumulators).
-template <int WI>
+// Workgroup = 4 waves = WPX x (4 / WPX) waves over (pixels, output channels); a wave owns PB x CB blocks of 32 pixels x 32
+// channels.  Two shapes, 64 output channels per workgroup in both:
+//   <PB 2, CB 2, WPX 4>  256 pixels per workgroup, 4 MFMAs per 4 LDS operand reads  -- large batches
+//   <PB 1, CB 1, WPX 2>   64 pixels per workgroup, 4x the workgroups                 -- small batches (the reference
+//                                                  trains with 16 samples: a 8x8 layer has 1024 pixels in total)
+template <int WI, int PB, int CB, int WPX, int KC>
 __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
                                                        int CI, int CO) {
-    using T = Tile<WI, 256>;
-    constexpr int KC = 8;
+    constexpr int WCO = 4 / WPX, TILE = 32 * PB * WPX;
+    static_assert(32 * CB * WCO == 64, "64 output channels per workgroup");
+    using T = Tile<WI, TILE>;
     constexpr int NIN = (KC * T::PLANE + 255) / 256, NWT = 9 * KC * 64 / 256;
     __shared__ float s_in[KC * T::PLANE];
     __shared__ float s_w[9 * KC * 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
+    const int wpx = wave % WPX, wco = wave / WPX;
     const int tile = blockIdx.x, n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR, co0 = blockIdx.y * 64;
 
-    f32x16 acc[2][2];
+    f32x16 acc[PB][CB];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < PB; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < CB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    int boff[2];
+    int boff[PB];
 #pragma unroll
-    for (int i = 0; i < 2; i++) boff[i] = T::halo(wave * 64 + i * 32 + lm);
+    for (int i = 0; i < PB; i++) boff[i] = T::halo((wpx * PB + i) * 32 + lm);
+    const int aoff = wco * CB * 32 + lm;
 
     // chunk-invariant source offsets of this thread's staging slots
     int off_in[NIN], ci_in[NIN];
@@ -116,27 +123,28 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
 #pragma unroll
             for (int k0 = 0; k0 < KC; k0 += 2) {
                 const int ci = k0 + kh;
-                const float a0 = s_w[(tap * KC + ci) * 64 + lm];
-                const float a1 = s_w[(tap * KC + ci) * 64 + lm + 32];
-                const float b0 = s_in[ci * T::PLANE + boff[0] + ky * T::TW + kx];
-                const float b1 = s_in[ci * T::PLANE + boff[1] + ky * T::TW + kx];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                float a[CB], b[PB];
+#pragma unroll
+                for (int j = 0; j < CB; j++) a[j] = s_w[(tap * KC + ci) * 64 + aoff + 32 * j];
+#pragma unroll
+                for (int i = 0; i < PB; i++) b[i] = s_in[ci * T::PLANE + boff[i] + ky * T::TW + kx];
+#pragma unroll
+                for (int i = 0; i < PB; i++)
+#pragma unroll
+                    for (int j = 0; j < CB; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[i], acc[i][j], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int q = wave * 64 + i * 32 + lm;
+    for (int i = 0; i < PB; i++) {
+        const int q = (wpx * PB + i) * 32 + lm;
         const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
         if (n >= N) continue;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < CB; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int co = co0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int co = co0 + (wco * CB + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (co < CO) out[(((size_t)n * CO + co) * WI + y) * WI + x] = acc[i][j][r] + (bias ? bias[co] : 0.0f);
             }
     }
@@ -212,42 +220,83 @@ __global__ void lgt_wreduce_kernel(const float* __restrict__ partial, int S, int
     gw[((size_t)co * CI + ci) * 9 + tap] = s;
 }
 
-// w[co][ci][tap] -> wpf[tap][ci][co] (forward) and wpd[8-tap][co][ci] (backward-data: taps mirrored, channels swapped)
-__global__ void lgt_pack_kernel(const float* __restrict__ w, int CI, int CO, float* __restrict__ wpf,
-                                float* __restrict__ wpd) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 9 * CI * CO) return;
+// w[co][ci][tap] -> wpf[tap][ci][co] (forward) and wpd[8-tap][co][ci] (backward-data: taps mirrored, channels swapped);
+// all conv layers in one launch
+struct PackTable { const float* w[8]; float* wpf[8]; float* wpd[8]; int ci[8], co[8]; unsigned end[8]; int n; };
+__global__ void lgt_pack_kernel(PackTable T) {
+    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    int l = 0;
+    while (l < T.n && g >= T.end[l]) l++;
+    if (l >= T.n) return;
+    const int e = (int)(g - (l ? T.end[l - 1] : 0u)), CI = T.ci[l], CO = T.co[l];
     const int tap = e % 9, ci = (e / 9) % CI, co = e / (9 * CI);
-    const float v = w[e];
-    wpf[((size_t)tap * CI + ci) * CO + co] = v;
-    wpd[((size_t)(8 - tap) * CO + co) * CI + ci] = v;
+    const float v = T.w[l][e];
+    T.wpf[l][((size_t)tap * CI + ci) * CO + co] = v;
+    T.wpd[l][((size_t)(8 - tap) * CO + co) * CI + ci] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm2d
-// one workgroup per channel: mean, biased variance (two passes), rstd; running statistics as nn.BatchNorm2d (momentum 0.1,
-// unbiased variance in the running estimate)
-__global__ __launch_bounds__(256) void lgt_bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, float eps,
-                                                           float momentum, float* __restrict__ mean,
-                                                           float* __restrict__ rstd, float* __restrict__ run_mean,
-                                                           float* __restrict__ run_var) {
+// Workgroup (c, s) reduces channel c over sample chunk s: count, mean and M2 = sum (x - chunk mean)^2 (two passes, the
+// second one hits L2).  The chunks are combined in index order with Chan's formula -- by the same workgroup when there
+// is one chunk, else by lgt_bn_finish_kernel: mean, biased variance -> rstd; running statistics as nn.BatchNorm2d
+// (momentum 0.1, unbiased variance in the running estimate).
+__device__ inline void bn_finish(int c, float cnt, float mu, float m2, float eps, float momentum, float* mean, float* rstd,
+                                 float* run_mean, float* run_var) {
+    const float var = m2 / cnt;
+    mean[c] = mu;
+    rstd[c] = 1.0f / sqrtf(var + eps);
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (cnt / (cnt > 1.0f ? cnt - 1.0f : 1.0f));
+}
+__global__ __launch_bounds__(256) void lgt_bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, int chunk,
+                                                           float eps, float momentum, float* __restrict__ part,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
     __shared__ float s_red[4];
     const int c = blockIdx.x, t = threadIdx.x;
-    const int M = N * HW;
+    const int na = blockIdx.y * chunk, nb = min(N, na + chunk), M = (nb - na) * HW;
+    const float* xc = x + ((size_t)na * C + c) * HW;
+    const size_t sn = (size_t)C * HW;
     float s = 0.0f;
-    for (int i = t; i < M; i += 256) s += x[((size_t)(i / HW) * C + c) * HW + i % HW];
+    for (int i = t; i < M; i += 256) s += xc[(size_t)(i / HW) * sn + i % HW];
     const float mu = block_sum(s, s_red) / (float)M;
     float v = 0.0f;
     for (int i = t; i < M; i += 256) {
-        const float d = x[((size_t)(i / HW) * C + c) * HW + i % HW] - mu;
+        const float d = xc[(size_t)(i / HW) * sn + i % HW] - mu;
         v += d * d;
     }
-    const float var = block_sum(v, s_red) / (float)M;
+    const float m2 = block_sum(v, s_red);
     if (t == 0) {
-        mean[c] = mu;
-        rstd[c] = 1.0f / sqrtf(var + eps);
-        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mu;
-        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        if (gridDim.y == 1) bn_finish(c, (float)M, mu, m2, eps, momentum, mean, rstd, run_mean, run_var);
+        else {
+            float* q = part + ((size_t)c * gridDim.y + blockIdx.y) * 3;
+            q[0] = (float)M; q[1] = mu; q[2] = m2;
+        }
     }
+}
+__global__ void lgt_bn_finish_kernel(const float* __restrict__ part, int C, int S, float eps, float momentum,
+                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                     float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* q = part + (size_t)c * S * 3;
+    float cnt = q[0], mu = q[1], m2 = q[2];
+    for (int k = 1; k < S; k++) {
+        const float nb = q[3 * k], mb = q[3 * k + 1], d = mb - mu, tot = cnt + nb;
+        mu += d * (nb / tot);
+        m2 += q[3 * k + 2] + d * d * (cnt * nb / tot);
+        cnt = tot;
+    }
+    bn_finish(c, cnt, mu, m2, eps, momentum, mean, rstd, run_mean, run_var);
+}
+// out[k] = sum_s part[k][s]   (k < K, fixed order)
+__global__ void lgt_rowsum_kernel(const float* __restrict__ part, int K, int S, float* __restrict__ o0, float* __restrict__ o1,
+                                  int K0) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.0f;
+    for (int j = 0; j < S; j++) s += part[(size_t)k * S + j];
+    if (k < K0) o0[k] = s; else o1[k - K0] = s;
 }
 
 __device__ inline float bn_relu(float x, float mu, float rs, float g, float b) { return fmaxf((x - mu) * rs * g + b, 0.0f); }
@@ -295,24 +344,26 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gam, const float* __restrict__ bet,
                                                                 const float* __restrict__ dmask, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int N, int C, int WI) {
+                                                                float* __restrict__ dbeta, float* __restrict__ part, int chunk,
+                                                                int N, int C, int WI) {
     __shared__ float s_red[4];
     const int c = blockIdx.x, t = threadIdx.x;
+    const int na = blockIdx.y * chunk, nb = min(N, na + chunk);
     const float mu = mean[c], rs = rstd[c], g = gam[c], b = bet[c];
     float sg = 0.0f, sb = 0.0f;
     if (!POOL) {
-        const int HW = WI * WI, M = N * HW;
+        const int HW = WI * WI, M = (nb - na) * HW;
         for (int i = t; i < M; i += 256) {
-            const size_t e = ((size_t)(i / HW) * C + c) * HW + i % HW;
+            const size_t e = ((size_t)(na + i / HW) * C + c) * HW + i % HW;
             const float xh = (x[e] - mu) * rs;
             const float dy = (xh * g + b > 0.0f) ? dout[e] : 0.0f;
             sg += dy * xh;
             sb += dy;
         }
     } else {
-        const int WO = WI / 2, HWO = WO * WO, M = N * HWO;
+        const int WO = WI / 2, HWO = WO * WO, M = (nb - na) * HWO;
         for (int i = t; i < M; i += 256) {
-            const int n = i / HWO, r = i % HWO, yo = r / WO, xo = r % WO;
+            const int n = na + i / HWO, r = i % HWO, yo = r / WO, xo = r % WO;
             const size_t nc = (size_t)n * C + c;
             const float* xp = x + (nc * WI + 2 * yo) * WI + 2 * xo;
             const float xh[4] = {(xp[0] - mu) * rs, (xp[1] - mu) * rs, (xp[WI] - mu) * rs, (xp[WI + 1] - mu) * rs};
@@ -326,7 +377,13 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
     }
     sg = block_sum(sg, s_red);
     sb = block_sum(sb, s_red);
-    if (t == 0) { dgamma[c] = sg; dbeta[c] = sb; }
+    if (t == 0) {
+        if (gridDim.y == 1) { dgamma[c] = sg; dbeta[c] = sb; }
+        else {   // part[0..C) rows = dgamma chunks, part[C..2C) rows = dbeta chunks; summed by lgt_rowsum_kernel
+            part[(size_t)c * gridDim.y + blockIdx.y] = sg;
+            part[(size_t)(C + c) * gridDim.y + blockIdx.y] = sb;
+        }
+    }
 }
 
 // dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M)
@@ -453,50 +510,68 @@ __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict
     }
 }
 
-// BatchNorm1d (batch statistics) + ReLU + Dropout keep mask; one thread per feature
-__global__ void lgt_bn1d_fwd_kernel(const float* __restrict__ U, const float* __restrict__ gam,
+// BatchNorm1d (batch statistics) + ReLU + Dropout keep mask.  Workgroup = 64 features x 16 row groups; a row group walks
+// the samples n = rg, rg + 16, ...; the 16 partial sums of a feature are added in index order by every thread.
+constexpr int kRG = 16;
+__device__ inline float rg_sum(float v, float (*s)[64], int f, int rg) {
+    __syncthreads();
+    s[rg][f] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRG; k++) t += s[k][f];
+    return t;
+}
+__global__ __launch_bounds__(64 * kRG) void lgt_bn1d_fwd_kernel(const float* __restrict__ U, const float* __restrict__ gam,
                                     const float* __restrict__ bet, const float* __restrict__ mask, float* __restrict__ Y,
                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                     float* __restrict__ run_var, int N, int O, float eps, float momentum) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= O) return;
+    __shared__ float s_p[kRG][64];
+    const int f = threadIdx.x, rg = threadIdx.y, o = min((int)blockIdx.x * 64 + f, O - 1);
+    const bool own = (int)blockIdx.x * 64 + f < O;
     float s = 0.0f;
-    for (int n = 0; n < N; n++) s += U[(size_t)n * O + o];
-    const float mu = s / (float)N;
+    for (int n = rg; n < N; n += kRG) s += U[(size_t)n * O + o];
+    const float mu = rg_sum(s, s_p, f, rg) / (float)N;
     float v = 0.0f;
-    for (int n = 0; n < N; n++) {
+    for (int n = rg; n < N; n += kRG) {
         const float d = U[(size_t)n * O + o] - mu;
         v += d * d;
     }
-    const float var = v / (float)N, rs = 1.0f / sqrtf(var + eps);
-    mean[o] = mu;
-    rstd[o] = rs;
-    run_mean[o] = (1.0f - momentum) * run_mean[o] + momentum * mu;
-    run_var[o] = (1.0f - momentum) * run_var[o] + momentum * var * ((float)N / (float)(N > 1 ? N - 1 : 1));
+    const float var = rg_sum(v, s_p, f, rg) / (float)N, rs = 1.0f / sqrtf(var + eps);
+    if (!own) return;
+    if (rg == 0) {
+        mean[o] = mu;
+        rstd[o] = rs;
+        run_mean[o] = (1.0f - momentum) * run_mean[o] + momentum * mu;
+        run_var[o] = (1.0f - momentum) * run_var[o] + momentum * var * ((float)N / (float)(N > 1 ? N - 1 : 1));
+    }
     const float g = gam[o], b = bet[o];
-    for (int n = 0; n < N; n++)
+    for (int n = rg; n < N; n += kRG)
         Y[(size_t)n * O + o] = fmaxf((U[(size_t)n * O + o] - mu) * rs * g + b, 0.0f) * mask[(size_t)n * O + o];
 }
 
-__global__ void lgt_bn1d_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ U,
+__global__ __launch_bounds__(64 * kRG) void lgt_bn1d_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ U,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gam, const float* __restrict__ bet,
                                     const float* __restrict__ mask, float* __restrict__ dU, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int N, int O) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= O) return;
+    __shared__ float s_p[kRG][64];
+    const int f = threadIdx.x, rg = threadIdx.y, o = min((int)blockIdx.x * 64 + f, O - 1);
+    const bool own = (int)blockIdx.x * 64 + f < O;
     const float mu = mean[o], rs = rstd[o], g = gam[o], b = bet[o];
     float sg = 0.0f, sb = 0.0f;
-    for (int n = 0; n < N; n++) {
+    for (int n = rg; n < N; n += kRG) {
         const float xh = (U[(size_t)n * O + o] - mu) * rs;
         const float dy = (xh * g + b > 0.0f) ? dY[(size_t)n * O + o] * mask[(size_t)n * O + o] : 0.0f;
         sg += dy * xh;
         sb += dy;
     }
-    dgamma[o] = sg;
-    dbeta[o] = sb;
+    sg = rg_sum(sg, s_p, f, rg);
+    sb = rg_sum(sb, s_p, f, rg);
+    if (!own) return;
+    if (rg == 0) { dgamma[o] = sg; dbeta[o] = sb; }
     const float invN = 1.0f / (float)N;
-    for (int n = 0; n < N; n++) {
+    for (int n = rg; n < N; n += kRG) {
         const float xh = (U[(size_t)n * O + o] - mu) * rs;
         const float dy = (xh * g + b > 0.0f) ? dY[(size_t)n * O + o] * mask[(size_t)n * O + o] : 0.0f;
         dU[(size_t)n * O + o] = g * rs * (dy - sb * invN - xh * sg * invN);
@@ -557,18 +632,23 @@ __global__ __launch_bounds__(256) void lgt_sumsq_kernel(const float* __restrict_
 
 struct AdamHp { float lr, beta1, beta2, eps, weight_decay, max_norm; };
 
-// clip_grad_norm_(max_norm) + torch.optim.Adam(weight_decay = L2 added to the gradient); state[0] = step count (float),
-// state[1] = total gradient norm of this step (before clipping)
-__global__ __launch_bounds__(256) void lgt_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                       float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                       const float* __restrict__ partial, int nparts,
-                                                       const AdamHp* __restrict__ hp_, float* __restrict__ state) {
-    const AdamHp hp = *hp_;
+// state[0] = step count (float), state[1] = total gradient norm of this step (before clipping).  One wave adds the
+// partial sums in index order and advances the step count when the optimizer runs.
+__global__ void lgt_norm_kernel(const float* __restrict__ partial, int nparts, int advance, float* __restrict__ state) {
     float ss = 0.0f;
     for (int k = 0; k < nparts; k++) ss += partial[k];
-    const float norm = sqrtf(ss);
-    float coef = hp.max_norm > 0.0f ? fminf(hp.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-    const float step = state[0] + 1.0f;
+    if (threadIdx.x == 0) {
+        state[1] = sqrtf(ss);
+        if (advance) state[0] += 1.0f;
+    }
+}
+// clip_grad_norm_(max_norm) + torch.optim.Adam(weight_decay = L2 added to the gradient)
+__global__ __launch_bounds__(256) void lgt_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                       const AdamHp* __restrict__ hp_, const float* __restrict__ state) {
+    const AdamHp hp = *hp_;
+    const float norm = state[1], step = state[0];
+    const float coef = hp.max_norm > 0.0f ? fminf(hp.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
     const float bc1 = 1.0f - powf(hp.beta1, step), bc2 = 1.0f - powf(hp.beta2, step);
     const float step_size = hp.lr / bc1, bc2s = sqrtf(bc2);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -580,19 +660,20 @@ __global__ __launch_bounds__(256) void lgt_adam_kernel(float* __restrict__ p, co
         v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + hp.eps));
     }
-    if (i == 0) state[2] = norm;
 }
-__global__ void lgt_step_kernel(float* state) { state[0] += 1.0f; state[1] = state[2]; }
 
-// keep mask of a dropout layer: 0 or 1/(1-p); counter-based hash of (seed, index)
-__global__ void lgt_mask_kernel(float* __restrict__ mask, size_t n, float p, uint64_t seed) {
+// keep masks of all dropout layers in one launch: 0 or 1/(1-p); counter-based hash of (seed, index)
+struct MaskTable { size_t end[8]; float p[8]; int n; };
+__global__ void lgt_mask_kernel(float* __restrict__ mask, MaskTable T, uint64_t seed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    int l = 0;
+    while (l < T.n && i >= T.end[l]) l++;
+    if (l >= T.n) return;
     uint64_t zz = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
     zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
     zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
     zz ^= zz >> 31;
-    const float u = (float)(zz >> 40) * (1.0f / 16777216.0f);
+    const float u = (float)(zz >> 40) * (1.0f / 16777216.0f), p = T.p[l];
     mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
 }
 
@@ -622,12 +703,13 @@ struct lg_trainer {
     size_t mask_fc[3] = {0, 0, 0};
     float *P_ = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *B = nullptr, *mean = nullptr, *rstd = nullptr;
     float *xin = nullptr, *labels = nullptr, *masks = nullptr;
-    float *dA[2] = {nullptr, nullptr}, *dX = nullptr, *partial = nullptr;
+    float *dA[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr}, *partial = nullptr, *bn_part = nullptr;
     size_t partial_floats = 0;
     float *att_a = nullptr, *gap = nullptr, *att_part = nullptr, *dfc[2] = {nullptr, nullptr}, *logits = nullptr, *dz = nullptr;
     float *loss = nullptr, *state = nullptr, *norm_part = nullptr;
     AdamHp* hp = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_w = nullptr;   // main chain; backward-weights branch
+    hipEvent_t ev_dx[8] = {}, ev_wg[8] = {};
     int64_t steps = 0;
     std::string err;
     std::vector<void*> allocs;
@@ -636,7 +718,16 @@ struct lg_trainer {
 namespace {
 
 constexpr int kNormParts = 256;
-constexpr int kMaxSplit = 128;
+constexpr int kMaxSplit = 512;                  // backward-weights pixel slices (partial sums) per layer
+constexpr size_t kMaxPartialFloats = 96u << 20; // ... bounded by 384 MiB of partial sums
+constexpr int kBnSplit = 64;                    // BatchNorm reduction: sample chunks per channel
+
+int wgrad_split(int ntiles, size_t nw) {
+    const size_t cap = std::max<size_t>(8, kMaxPartialFloats / nw);
+    return (int)std::min<size_t>(std::min<size_t>((size_t)ntiles, (size_t)kMaxSplit), cap);
+}
+// sample chunks of the BatchNorm reductions: enough workgroups to fill the chip, never more chunks than samples
+int bn_chunks(int N, int C) { return N < 64 ? 1 : std::max(1, std::min(std::min(N / 4, kBnSplit), 2048 / C)); }
 
 #define TR_HIP(call)                                                                                     \
     do {                                                                                                 \
@@ -658,14 +749,27 @@ int dalloc(lg_trainer* tr, float** p, size_t floats) {
     return LG_OK;
 }
 
-void launch_conv(int wi, dim3 grid, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N,
-                 int CI, int CO) {
+// workgroups of the large-tile shape below which the small-tile shape is launched (256 CUs x 2 resident workgroups)
+constexpr int kSmallConvBelow = 512;
+int conv_tiles(int wi, int N, int tile);
+void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N, int CI,
+                 int CO) {
+    const unsigned cb = (unsigned)((CO + 63) / 64);
+    const bool small = conv_tiles(wi, N, 256) * (int)cb < kSmallConvBelow;
+#define LGT_CONV(W)                                                                                                    \
+    if (small)                                                                                                         \
+        hipLaunchKernelGGL((lgt_conv_kernel<W, 1, 1, 2, 16>), dim3(conv_tiles(W, N, 64), cb), dim3(256), 0, s, in, wp, bias, \
+                           out, N, CI, CO);                                                                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL((lgt_conv_kernel<W, 2, 2, 4, 8>), dim3(conv_tiles(W, N, 256), cb), dim3(256), 0, s, in, wp, bias, \
+                           out, N, CI, CO);
     switch (wi) {
-        case 32: hipLaunchKernelGGL(lgt_conv_kernel<32>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
-        case 16: hipLaunchKernelGGL(lgt_conv_kernel<16>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
-        case 8: hipLaunchKernelGGL(lgt_conv_kernel<8>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
-        default: hipLaunchKernelGGL(lgt_conv_kernel<4>, grid, dim3(256), 0, s, in, wp, bias, out, N, CI, CO); break;
+        case 32: LGT_CONV(32) break;
+        case 16: LGT_CONV(16) break;
+        case 8: LGT_CONV(8) break;
+        default: LGT_CONV(4) break;
     }
+#undef LGT_CONV
 }
 void launch_wgrad(int wi, dim3 grid, hipStream_t s, const float* a, const float* dx, float* partial, int N, int CI, int CO,
                   int ntiles) {
@@ -769,10 +873,11 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
         A(&L.wpf, (size_t)9 * L.ci * L.co);
         A(&L.wpd, (size_t)9 * L.ci * L.co);
         max_act = std::max(max_act, std::max(full, N * L.ci * L.wi * L.wi));
-        const int tiles = std::min(conv_tiles(L.wi, max_batch, 128), kMaxSplit);
+        const int tiles = wgrad_split(conv_tiles(L.wi, max_batch, 128), (size_t)9 * L.ci * L.co);
         tr->partial_floats = std::max(tr->partial_floats, (size_t)tiles * 9 * L.ci * L.co);
     }
-    A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX, max_act); A(&tr->partial, tr->partial_floats);
+    A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX[0], max_act); A(&tr->dX[1], max_act);
+    A(&tr->partial, tr->partial_floats); A(&tr->bn_part, (size_t)1024 * kBnSplit * 3);
     A(&tr->att_a, N * tr->P); A(&tr->gap, N * F); A(&tr->att_part, N * (F + 1));
     A(&tr->dfc[0], N * F); A(&tr->dfc[1], N * F); A(&tr->logits, N); A(&tr->dz, N);
     for (int k = 0; k < 4; k++) { A(&tr->fc[k].u, N * tr->fc[k].out); if (k < 3) A(&tr->fc[k].y, N * tr->fc[k].out); }
@@ -781,6 +886,10 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     A(&hp, sizeof(AdamHp) / sizeof(float));
     tr->hp = (AdamHp*)hp;
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
+    if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream_w, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
+    for (int k = 0; k < 8 && rc == LG_OK; k++)
+        if (hipEventCreateWithFlags(&tr->ev_dx[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&tr->ev_wg[k], hipEventDisableTiming) != hipSuccess) rc = LG_ERR_HIP;
     if (rc != LG_OK) {
         for (void* q : tr->allocs) hipFree(q);
         delete tr;
@@ -798,6 +907,11 @@ int lg_train_destroy(lg_trainer* tr) {
     hipSetDevice(tr->device);
     hipDeviceSynchronize();
     if (tr->stream) hipStreamDestroy(tr->stream);
+    if (tr->stream_w) hipStreamDestroy(tr->stream_w);
+    for (int k = 0; k < 8; k++) {
+        if (tr->ev_dx[k]) hipEventDestroy(tr->ev_dx[k]);
+        if (tr->ev_wg[k]) hipEventDestroy(tr->ev_wg[k]);
+    }
     for (void* q : tr->allocs) hipFree(q);
     delete tr;
     return LG_OK;
@@ -864,28 +978,36 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
     if (masks) {
         TR_HIP(hipMemcpyAsync(tr->masks, masks, (size_t)N * mrow * 4, hipMemcpyDeviceToDevice, s));
     } else {
+        MaskTable mt = {};
         for (auto& L : tr->layers)
-            if (L.pool) {
-                const size_t n = (size_t)N * L.co;
-                hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tr->masks + (size_t)N * L.mask, n,
-                                   tr->drop2d_p, seed * 0x100000001B3ull + L.mask + 0x51ull * (uint64_t)tr->steps);
-            }
-        for (int k = 0; k < 3; k++) {
-            const size_t n = (size_t)N * tr->fc[k].out;
-            hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tr->masks + (size_t)N * tr->fc[k].mask, n,
-                               tr->drop_p[k], seed * 0x100000001B3ull + tr->fc[k].mask + 0x51ull * (uint64_t)tr->steps);
-        }
+            if (L.pool) { mt.end[mt.n] = (size_t)N * (L.mask + L.co); mt.p[mt.n++] = tr->drop2d_p; }
+        for (int k = 0; k < 3; k++) { mt.end[mt.n] = (size_t)N * (tr->fc[k].mask + tr->fc[k].out); mt.p[mt.n++] = tr->drop_p[k]; }
+        hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv((size_t)N * mrow, 256)), dim3(256), 0, s, tr->masks, mt,
+                           seed * 0x100000001B3ull + 0x51ull * (uint64_t)tr->steps);
     }
-    TR_HIP(hipMemsetAsync(tr->G, 0, tr->n_params * 4, s));   // conv / pre-BN linear biases: exact zero gradient (see DESIGN)
+    TR_HIP(hipMemsetAsync(tr->G, 0, tr->n_params * 4, s));   // conv biases: exact zero gradient (see DESIGN)
+    {
+        PackTable pt = {};
+        unsigned end = 0;
+        for (auto& L : tr->layers) {
+            const int k = pt.n++;
+            pt.w[k] = tr->P_ + L.w; pt.wpf[k] = L.wpf; pt.wpd[k] = L.wpd; pt.ci[k] = L.ci; pt.co[k] = L.co;
+            end += (unsigned)(9 * L.ci * L.co);
+            pt.end[k] = end;
+        }
+        hipLaunchKernelGGL(lgt_pack_kernel, dim3(cdiv(end, 256)), dim3(256), 0, s, pt);
+    }
 
     // ---------------- forward
     const float* a = tr->xin;
     for (auto& L : tr->layers) {
-        const size_t nw = (size_t)9 * L.ci * L.co;
-        hipLaunchKernelGGL(lgt_pack_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, tr->P_ + L.w, L.ci, L.co, L.wpf, L.wpd);
-        launch_conv(L.wi, dim3(conv_tiles(L.wi, N, 256), cdiv(L.co, 64)), s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
-        hipLaunchKernelGGL(lgt_bn_stats_kernel, dim3(L.co), dim3(256), 0, s, L.x, N, L.co, L.wi * L.wi, eps, mom,
-                           tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
+        launch_conv(L.wi, s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
+        const int S = bn_chunks(N, L.co), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
+        hipLaunchKernelGGL(lgt_bn_stats_kernel, dim3(L.co, Sy), dim3(256), 0, s, L.x, N, L.co, L.wi * L.wi, chunk, eps, mom,
+                           tr->bn_part, tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
+        if (Sy > 1)
+            hipLaunchKernelGGL(lgt_bn_finish_kernel, dim3(cdiv(L.co, 64)), dim3(64), 0, s, tr->bn_part, L.co, Sy, eps, mom,
+                               tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
         if (L.pool) {
             const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
             hipLaunchKernelGGL(lgt_bn_act_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->mean + L.st,
@@ -906,7 +1028,7 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
         hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(f.out, 4), cdiv(N, 16)), dim3(256), 0, s, fin, tr->P_ + f.w,
                            tr->P_ + f.b, k < 3 ? f.u : tr->logits, N, f.in, f.out);
         if (k < 3) {
-            hipLaunchKernelGGL(lgt_bn1d_fwd_kernel, dim3(cdiv(f.out, 64)), dim3(64), 0, s, f.u, tr->P_ + f.g, tr->P_ + f.be,
+            hipLaunchKernelGGL(lgt_bn1d_fwd_kernel, dim3(cdiv(f.out, 64)), dim3(64, kRG), 0, s, f.u, tr->P_ + f.g, tr->P_ + f.be,
                                tr->masks + (size_t)N * f.mask, f.y, tr->mean + f.st, tr->rstd + f.st, tr->B + f.rm,
                                tr->B + f.rv, N, f.out, eps, mom);
             fin = f.y;
@@ -926,7 +1048,7 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
         if (k > 0) {
             TrainFc& p = tr->fc[k - 1];   // dxk = gradient at p.y -> through dropout / ReLU / BN1d to p.u
             float* du = tr->dfc[1];
-            hipLaunchKernelGGL(lgt_bn1d_bwd_kernel, dim3(cdiv(p.out, 64)), dim3(64), 0, s, dxk, p.u, tr->mean + p.st,
+            hipLaunchKernelGGL(lgt_bn1d_bwd_kernel, dim3(cdiv(p.out, 64)), dim3(64, kRG), 0, s, dxk, p.u, tr->mean + p.st,
                                tr->rstd + p.st, tr->P_ + p.g, tr->P_ + p.be, tr->masks + (size_t)N * p.mask, du, tr->G + p.g,
                                tr->G + p.be, N, p.out);
             dy = du;
@@ -940,58 +1062,69 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
                        tr->dA[0], tr->att_part);
     if (spatial)
         hipLaunchKernelGGL(lgt_colsum_kernel, dim3(cdiv(F + 1, 64)), dim3(64), 0, s, tr->att_part, N, F + 1, tr->G + tr->att_w);
-    // encoder
+    // encoder.  Main chain per layer: BN backward (reduce, dx) -> backward-data convolution; the backward-weights
+    // convolution of the layer (+ the ordered sum of its pixel slices) runs beside it on the second stream.  dX is double
+    // buffered: layer li's dX is rewritten by layer li-2, which first waits for layer li's backward-weights.
+    hipStream_t sw = tr->stream_w;
     int cur = 0;
-    for (int li = (int)tr->layers.size() - 1; li >= 0; li--) {
+    const int nl = (int)tr->layers.size();
+    for (int li = nl - 1; li >= 0; li--) {
         TrainLayer& L = tr->layers[li];
         const float* ain = li == 0 ? tr->xin : tr->layers[li - 1].out;
         const float* dm = L.pool ? tr->masks + (size_t)N * L.mask : nullptr;
         const float *mu = tr->mean + L.st, *rs = tr->rstd + L.st, *g = tr->P_ + L.g, *be = tr->P_ + L.be;
+        float* dXl = tr->dX[li & 1];
+        if (li + 2 < nl) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li + 2], 0));
+        const int S = bn_chunks(N, L.co), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         if (L.pool) {
-            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, N, L.co, L.wi);
+            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, N, L.co, L.wi);
+        } else {
+            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<false>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
+                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, N, L.co, L.wi);
+        }
+        if (Sy > 1)
+            hipLaunchKernelGGL(lgt_rowsum_kernel, dim3(cdiv(2 * L.co, 64)), dim3(64), 0, s, tr->bn_part, 2 * L.co, Sy, tr->G + L.g,
+                               tr->G + L.be, L.co);
+        if (L.pool) {
             const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
             hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, tr->dX, N, L.co, L.wi);
+                               tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
         } else {
-            hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<false>, dim3(L.co), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, N, L.co, L.wi);
             const size_t n = (size_t)N * L.co * L.wi * L.wi;
             hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, tr->dX, N, L.co, L.wi);
+                               tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
         }
-        const int ntiles = conv_tiles(L.wi, N, 128), S = std::min(ntiles, kMaxSplit);
-        launch_wgrad(L.wi, dim3(S, cdiv(L.co, 64), cdiv(L.ci, 64)), s, ain, tr->dX, tr->partial, N, L.ci, L.co, ntiles);
+        TR_HIP(hipEventRecord(tr->ev_dx[li], s));
+        TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));
         const size_t nw = (size_t)9 * L.ci * L.co;
-        hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, tr->partial, S, L.ci, L.co, tr->G + L.w);
+        const int ntiles = conv_tiles(L.wi, N, 128), Sw = wgrad_split(ntiles, nw);
+        launch_wgrad(L.wi, dim3(Sw, cdiv(L.co, 64), cdiv(L.ci, 64)), sw, ain, dXl, tr->partial, N, L.ci, L.co, ntiles);
+        hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, sw, tr->partial, Sw, L.ci, L.co, tr->G + L.w);
+        TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
         if (li > 0) {   // backward-data: a convolution of dX with the mirrored, channel-swapped weights
-            launch_conv(L.wi, dim3(conv_tiles(L.wi, N, 256), cdiv(L.ci, 64)), s, tr->dX, L.wpd, (const float*)nullptr,
-                        tr->dA[cur ^ 1], N, L.co, L.ci);
+            launch_conv(L.wi, s, dXl, L.wpd, (const float*)nullptr, tr->dA[cur ^ 1], N, L.co, L.ci);
             cur ^= 1;
         }
     }
+    for (int li = 0; li < std::min(2, nl); li++) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li], 0));   // sw is in order: 0 covers all
     // ---------------- optimizer
     hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
+    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(1), 0, s, tr->norm_part, kNormParts, apply_update ? 1 : 0, tr->state);
     if (apply_update) {
         hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
-                           tr->n_params, tr->norm_part, kNormParts, tr->hp, tr->state);
-        hipLaunchKernelGGL(lgt_step_kernel, dim3(1), dim3(1), 0, s, tr->state);
+                           tr->n_params, tr->hp, tr->state);
         tr->steps++;
     }
     if (logits_dev) TR_HIP(hipMemcpyAsync(logits_dev, tr->logits, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
     TR_HIP(hipGetLastError());
     if (loss_host || grad_norm_host) {
-        float l = 0.f;
+        float l = 0.f, st[4] = {0.f, 0.f, 0.f, 0.f};
         TR_HIP(hipMemcpyAsync(&l, tr->loss, 4, hipMemcpyDeviceToHost, s));
-        float parts[kNormParts];
-        TR_HIP(hipMemcpyAsync(parts, tr->norm_part, sizeof(parts), hipMemcpyDeviceToHost, s));
+        TR_HIP(hipMemcpyAsync(st, tr->state, 16, hipMemcpyDeviceToHost, s));
         TR_HIP(hipStreamSynchronize(s));
         if (loss_host) *loss_host = l;
-        if (grad_norm_host) {
-            float ss = 0.f;
-            for (int k = 0; k < kNormParts; k++) ss += parts[k];
-            *grad_norm_host = sqrtf(ss);
-        }
+        if (grad_norm_host) *grad_norm_host = st[1];
     }
     return LG_OK;
 }
