@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--node-steps", type=int, default=3,
                     help="extra, untimed-for-the-headline leg: steps of the WHOLE node sequence (batched leaf selection + "
                          "grasp selection) reported as `node_sequence` (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=30,
+                    help="N=1 only: optimisation steps of the GraspPointCNN training step (lg_train_step: forward + backward + "
+                         "clip + Adam) timed at the reference's batch size 16 and at 1024, reported as `train_step` (0 = skip)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: print every step's wall time to stderr "
                                                             "(adds a device sync per step; not the headline mode)")
     args = ap.parse_args()
@@ -321,6 +324,43 @@ def main():
                                                 "selection incl. CNN, int16 labels + depth resident in HBM"}
             except Exception as e:  # noqa: BLE001
                 out["node_sequence"] = {"error": str(e)}
+        if world == 1 and args.train_steps > 0 and not args.no_cnn:
+            # secondary figure (never `value`): SURVEY 8f row 4, the inner loop body of scripts/train_model.py:247-265
+            try:
+                import ctypes as C
+                from leafgrasp_amd._lib import lib as _lib
+                from leafgrasp_amd.trainer import GraspTrainer
+                ts = {}
+                for nb in (16, 1024):
+                    tr = GraspTrainer(dev, max_batch=nb)
+                    base = torch.from_numpy(SI.synthetic_patches(256, seed=1)).to(dev)
+                    xb = base.repeat((nb + 255) // 256, 1, 1, 1)[:nb].contiguous()
+                    yb = (torch.arange(nb, device=dev) % 3 == 0).float()
+                    loss = C.c_float()
+
+                    def one(sync):
+                        rc = _lib.lg_train_step(tr._h, xb.data_ptr(), yb.data_ptr(), nb, None, 1, C.byref(tr.hp), 1,
+                                                C.byref(loss) if sync else None, None, None)
+                        if rc != 0:
+                            raise RuntimeError(_lib.lg_train_last_error(tr._h).decode())
+                    torch.cuda.synchronize(dev)
+                    for _ in range(3):
+                        one(False)
+                    one(True)
+                    t_t = time.perf_counter()
+                    for _ in range(args.train_steps - 1):
+                        one(False)
+                    one(True)
+                    dt_t = (time.perf_counter() - t_t) / args.train_steps
+                    ts[f"batch_{nb}"] = {"ms_per_step": round(dt_t * 1e3, 4), "samples_per_s": round(nb / dt_t, 1)}
+                    del tr
+                ts["what"] = ("GraspPointCNN([64,128,256], spatial attention) forward (train mode) + BCEWithLogits + backward + "
+                              "clip_grad_norm + Adam per step, fp32 MFMA convolutions, patches resident in HBM, dropout masks "
+                              "drawn on the device; batch 16 = scripts/train_model.py:207")
+                ts["steps"] = args.train_steps
+                out["train_step"] = ts
+            except Exception as e:  # noqa: BLE001
+                out["train_step"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -26,6 +26,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ float lgt_zero_pad[4];  // zero-initialised source for padded / out-of-range direct-to-LDS lanes
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ tiles
@@ -52,6 +54,19 @@ __device__ inline float block_sum(float v, float* s_red) {   // 256 threads; res
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// Workgroups of 64 columns x kRG row groups: a row group walks rows rg, rg + kRG, ...; the kRG partial sums of a column
+// are added in index order by every thread of the column.
+constexpr int kRG = 16;
+__device__ inline float rg_sum(float v, float (*s)[64], int f, int rg) {
+    __syncthreads();
+    s[rg][f] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRG; k++) t += s[k][f];
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------ conv fwd / dgrad
 // out[n][co][y][x] = bias[co] + sum_{tap,ci} wp[tap][ci][co] * in[n][ci][y+ky-1][x+kx-1]     (zero padding)
 // Workgroup = 4 waves = WPX x (4 / WPX) waves over (pixels, output channels); a wave owns PB x CB blocks of 32 pixels x 32
@@ -66,9 +81,11 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
     constexpr int WCO = 4 / WPX, TILE = 32 * PB * WPX;
     static_assert(32 * CB * WCO == 64, "64 output channels per workgroup");
     using T = Tile<WI, TILE>;
-    constexpr int NIN = (KC * T::PLANE + 255) / 256, NWT = 9 * KC * 64 / 256;
-    __shared__ float s_in[KC * T::PLANE];
-    __shared__ float s_w[9 * KC * 64];
+    constexpr int IN_ELEMS = KC * T::PLANE, NIN = (IN_ELEMS + 255) / 256, IN_PAD = NIN * 256;
+    constexpr int W4_ELEMS = 9 * KC * 16, NW4 = (W4_ELEMS + 255) / 256;
+    constexpr int BUF = IN_PAD + NW4 * 1024;   // floats per stage
+    // one shared object, two stages of [input halo tile | weights], both filled by global_load_lds in load order
+    __shared__ __attribute__((aligned(16))) float s_buf[2 * BUF];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
     const int wpx = wave % WPX, wco = wave / WPX;
     const int tile = blockIdx.x, n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR, co0 = blockIdx.y * 64;
@@ -85,38 +102,52 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
     for (int i = 0; i < PB; i++) boff[i] = T::halo((wpx * PB + i) * 32 + lm);
     const int aoff = wco * CB * 32 + lm;
 
-    // chunk-invariant source offsets of this thread's staging slots
-    int off_in[NIN], ci_in[NIN];
+    // Direct-to-LDS staging: chunk c+1 streams into the other stage while the MFMA loop works on chunk c.  The LDS
+    // destination of one wave instruction is a wave-uniform base + lane * size, i.e. slot idx = t + 256 j lands at
+    // float idx (input) / float4 idx (weights): the images are linear in idx.  Zero padding of the convolution, channels
+    // past CI / CO and unused slots are fetched from a zeroed device word.  Source offsets are chunk-invariant apart from
+    // the channel base and computed once.
+    int off_in[NIN], ci_in[NIN], off_w[NW4], ci_w[NW4];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
         const int idx = t + 256 * j, ci = idx / T::PLANE, r = idx % T::PLANE;
         const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
         const int gy = y0 - 1 + ry, gx = rx - 1, n = n0 + ts;
-        const bool ok = idx < KC * T::PLANE && n < N && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
+        const bool ok = idx < IN_ELEMS && n < N && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
         off_in[j] = ok ? ((n * CI + ci) * WI + gy) * WI + gx : -1;
         ci_in[j] = ci;
     }
-    float r_in[NIN], r_w[NWT];
-    auto load_chunk = [&](int c0) {
 #pragma unroll
-        for (int j = 0; j < NIN; j++)
-            r_in[j] = (off_in[j] >= 0 && c0 + ci_in[j] < CI) ? in[(size_t)off_in[j] + (size_t)c0 * WI * WI] : 0.0f;
+    for (int j = 0; j < NW4; j++) {
+        const int idx = t + 256 * j, q = idx & 15, rest = idx >> 4, ci = rest % KC, tap = rest / KC;
+        off_w[j] = (idx < W4_ELEMS && co0 + 4 * q < CO) ? (tap * CI + ci) * CO + co0 + 4 * q : -1;
+        ci_w[j] = ci;
+    }
+    auto issue_chunk = [&](int c0, int stage) {
+        float* sb = s_buf + stage * BUF;
+        const float* in_c = in + (size_t)c0 * WI * WI;
+        const float* w_c = wp + (size_t)c0 * CO;
 #pragma unroll
-        for (int j = 0; j < NWT; j++) {
-            const int idx = t + 256 * j, co = idx & 63, rest = idx >> 6, ci = rest % KC, tap = rest / KC;
-            r_w[j] = (c0 + ci < CI && co0 + co < CO) ? wp[((size_t)tap * CI + c0 + ci) * CO + co0 + co] : 0.0f;
+        for (int j = 0; j < NIN; j++) {
+            const float* src = (off_in[j] >= 0 && c0 + ci_in[j] < CI) ? in_c + off_in[j] : lgt_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NW4; j++) {
+            const float* src = (off_w[j] >= 0 && c0 + ci_w[j] < CI) ? w_c + off_w[j] : lgt_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + IN_PAD + 4 * (256 * j + 64 * wave)),
+                                             16, 0, 0);
         }
     };
-    load_chunk(0);
-    for (int c0 = 0; c0 < CI; c0 += KC) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NIN; j++)
-            if (t + 256 * j < KC * T::PLANE) s_in[t + 256 * j] = r_in[j];
-#pragma unroll
-        for (int j = 0; j < NWT; j++) s_w[t + 256 * j] = r_w[j];
-        __syncthreads();
-        if (c0 + KC < CI) load_chunk(c0 + KC);
+    issue_chunk(0, 0);
+    int stage = 0;
+    for (int c0 = 0; c0 < CI; c0 += KC, stage ^= 1) {
+        __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
+        if (c0 + KC < CI) issue_chunk(c0 + KC, stage ^ 1);
+        const float* s_in = s_buf + stage * BUF;
+        const float* s_w = s_in + IN_PAD;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap % 3;
@@ -152,12 +183,14 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------ conv wgrad
 // partial[s][tap][ci][co] = sum over the pixel tiles of slice s of a[n][ci][y+ky-1][x+kx-1] * dx[n][co][y][x]
-// Workgroup: 64 ci x 64 co (wave: 32 x 32, nine tap accumulators), 128 pixels per K tile.
+// Workgroup: 64 ci x 64 co (wave: 32 x 32, nine tap accumulators), kWgTile pixels per K tile; LDS and registers sized for
+// two workgroups per CU (one workgroup stages while the other multiplies).
+constexpr int kWgTile = 64;
 template <int WI>
-__global__ __launch_bounds__(256) void lgt_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dx,
+__global__ __launch_bounds__(256, 2) void lgt_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dx,
                                                         float* __restrict__ partial, int N, int CI, int CO, int ntiles) {
-    using T = Tile<WI, 128>;
-    constexpr int SD = 129, SI = T::PLANE | 1;
+    using T = Tile<WI, kWgTile>;
+    constexpr int SD = kWgTile + 1, SI = T::PLANE | 1;
     __shared__ float s_d[64 * SD];
     __shared__ float s_i[64 * SI];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
@@ -174,8 +207,8 @@ __global__ __launch_bounds__(256) void lgt_wgrad_kernel(const float* __restrict_
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR;
         __syncthreads();
-        for (int idx = t; idx < 64 * 128; idx += 256) {
-            const int co = idx >> 7, q = idx & 127;
+        for (int idx = t; idx < 64 * kWgTile; idx += 256) {
+            const int co = idx / kWgTile, q = idx % kWgTile;
             const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
             s_d[co * SD + q] = (n < N && co0 + co < CO) ? dx[(((size_t)n * CO + co0 + co) * WI + y) * WI + x] : 0.0f;
         }
@@ -189,7 +222,7 @@ __global__ __launch_bounds__(256) void lgt_wgrad_kernel(const float* __restrict_
         __syncthreads();
         if (active) {
 #pragma unroll 4
-            for (int q0 = 0; q0 < 128; q0 += 2) {
+            for (int q0 = 0; q0 < kWgTile; q0 += 2) {
                 const int q = q0 + kh;
                 const float b = s_d[(wc * 32 + lm) * SD + q];
                 const float* ai = s_i + (wi * 32 + lm) * SI + T::halo(q);
@@ -428,24 +461,30 @@ __global__ void lgt_bn_bwd_dx_kernel(const float* __restrict__ x, const float* _
 __global__ __launch_bounds__(256) void lgt_att_fwd_kernel(const float* __restrict__ h, const float* __restrict__ wa,
                                                           const float* __restrict__ ba, int spatial, int F, int P,
                                                           float* __restrict__ a, float* __restrict__ g) {
-    __shared__ float s_a[64];
+    __shared__ float s_a[64], s_p[256];
     const int n = blockIdx.x, t = threadIdx.x;
     const float* hn = h + (size_t)n * F * P;
+    const int p = t % P, cg = t / P, G = 256 / P;     // P divides 256 (1, 4, 16, 64)
+    float s = 0.0f;
+    if (spatial)
+        for (int c = cg; c < F; c += G) s += wa[c] * hn[c * P + p];
+    s_p[t] = s;
+    __syncthreads();
     if (t < P) {
         float v = 1.0f;
         if (spatial) {
-            float s = ba[0];
-            for (int c = 0; c < F; c++) s += wa[c] * hn[c * P + t];
-            v = 1.0f / (1.0f + expf(-s));
+            float z = ba[0];
+            for (int k = 0; k < G; k++) z += s_p[k * P + t];
+            v = 1.0f / (1.0f + expf(-z));
         }
         s_a[t] = v;
         a[(size_t)n * P + t] = v;
     }
     __syncthreads();
     for (int c = t; c < F; c += 256) {
-        float s = 0.0f;
-        for (int p = 0; p < P; p++) s += hn[c * P + p] * s_a[p];
-        g[(size_t)n * F + c] = s / (float)P;
+        float z = 0.0f;
+        for (int q = 0; q < P; q++) z += hn[c * P + q] * s_a[q];
+        g[(size_t)n * F + c] = z / (float)P;
     }
 }
 
@@ -455,44 +494,48 @@ __global__ __launch_bounds__(256) void lgt_att_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dg, const float* __restrict__ wa,
                                                           int spatial, int F, int P, float* __restrict__ dh,
                                                           float* __restrict__ part) {
-    __shared__ float s_a[64], s_ds[64];
+    __shared__ float s_a[64], s_ds[64], s_p[256];
     const int n = blockIdx.x, t = threadIdx.x;
     const float* hn = h + (size_t)n * F * P;
     const float* dgn = dg + (size_t)n * F;
+    const int p = t % P, cg = t / P, G = 256 / P;
+    float s = 0.0f;
+    if (spatial)
+        for (int c = cg; c < F; c += G) s += dgn[c] * hn[c * P + p];
+    s_p[t] = s;
+    __syncthreads();
     if (t < P) {
         const float av = a[(size_t)n * P + t];
-        float ds = 0.0f;
-        if (spatial) {
-            float s = 0.0f;
-            for (int c = 0; c < F; c++) s += dgn[c] * hn[c * P + t];
-            ds = s / (float)P * av * (1.0f - av);
-        }
+        float z = 0.0f;
+        for (int k = 0; k < G; k++) z += s_p[k * P + t];
         s_a[t] = av;
-        s_ds[t] = ds;
+        s_ds[t] = spatial ? z / (float)P * av * (1.0f - av) : 0.0f;
     }
     __syncthreads();
     for (int c = t; c < F; c += 256) {
         const float d = dgn[c] / (float)P, w = spatial ? wa[c] : 0.0f;
         float pw = 0.0f;
-        for (int p = 0; p < P; p++) {
-            dh[((size_t)n * F + c) * P + p] = d * s_a[p] + s_ds[p] * w;
-            pw += s_ds[p] * hn[c * P + p];
+        for (int q = 0; q < P; q++) {
+            dh[((size_t)n * F + c) * P + q] = d * s_a[q] + s_ds[q] * w;
+            pw += s_ds[q] * hn[c * P + q];
         }
         if (spatial) part[(size_t)n * (F + 1) + c] = pw;
     }
     if (spatial && t == 0) {
-        float s = 0.0f;
-        for (int p = 0; p < P; p++) s += s_ds[p];
-        part[(size_t)n * (F + 1) + F] = s;
+        float z = 0.0f;
+        for (int q = 0; q < P; q++) z += s_ds[q];
+        part[(size_t)n * (F + 1) + F] = z;
     }
 }
 
-__global__ void lgt_colsum_kernel(const float* __restrict__ part, int N, int K, float* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+__global__ __launch_bounds__(64 * kRG) void lgt_colsum_kernel(const float* __restrict__ part, int N, int K,
+                                                              float* __restrict__ out) {
+    __shared__ float s_p[kRG][64];
+    const int f = threadIdx.x, rg = threadIdx.y, k = min((int)blockIdx.x * 64 + f, K - 1);
     float s = 0.0f;
-    for (int n = 0; n < N; n++) s += part[(size_t)n * K + k];
-    out[k] = s;
+    for (int n = rg; n < N; n += kRG) s += part[(size_t)n * K + k];
+    s = rg_sum(s, s_p, f, rg);
+    if (rg == 0 && (int)blockIdx.x * 64 + f < K) out[k] = s;
 }
 
 // Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples)
@@ -510,18 +553,7 @@ __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict
     }
 }
 
-// BatchNorm1d (batch statistics) + ReLU + Dropout keep mask.  Workgroup = 64 features x 16 row groups; a row group walks
-// the samples n = rg, rg + 16, ...; the 16 partial sums of a feature are added in index order by every thread.
-constexpr int kRG = 16;
-__device__ inline float rg_sum(float v, float (*s)[64], int f, int rg) {
-    __syncthreads();
-    s[rg][f] = v;
-    __syncthreads();
-    float t = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kRG; k++) t += s[k][f];
-    return t;
-}
+// BatchNorm1d (batch statistics) + ReLU + Dropout keep mask.  Workgroup = 64 features x kRG row groups over the samples.
 __global__ __launch_bounds__(64 * kRG) void lgt_bn1d_fwd_kernel(const float* __restrict__ U, const float* __restrict__ gam,
                                     const float* __restrict__ bet, const float* __restrict__ mask, float* __restrict__ Y,
                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
@@ -579,28 +611,32 @@ __global__ __launch_bounds__(64 * kRG) void lgt_bn1d_bwd_kernel(const float* __r
 }
 
 // dX[n][i] = sum_o dY[n][o] W[o][i]
-__global__ void lgt_fc_bwd_x_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
-                                    int N, int I, int O) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-    if (i >= I) return;
+__global__ __launch_bounds__(64 * kRG) void lgt_fc_bwd_x_kernel(const float* __restrict__ dY, const float* __restrict__ W,
+                                                                float* __restrict__ dX, int N, int I, int O) {
+    __shared__ float s_p[kRG][64];
+    const int f = threadIdx.x, rg = threadIdx.y, i = min((int)blockIdx.x * 64 + f, I - 1), n = blockIdx.y;
     float s = 0.0f;
-    for (int o = 0; o < O; o++) s += dY[(size_t)n * O + o] * W[(size_t)o * I + i];
-    dX[(size_t)n * I + i] = s;
+    for (int o = rg; o < O; o += kRG) s += dY[(size_t)n * O + o] * W[(size_t)o * I + i];
+    s = rg_sum(s, s_p, f, rg);
+    if (rg == 0 && (int)blockIdx.x * 64 + f < I) dX[(size_t)n * I + i] = s;
 }
 
 // dW[o][i] = sum_n dY[n][o] X[n][i], db[o] = sum_n dY[n][o]
-__global__ void lgt_fc_bwd_w_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dW,
-                                    float* __restrict__ db, int N, int I, int O) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
-    if (i >= I) return;
+__global__ __launch_bounds__(64 * kRG) void lgt_fc_bwd_w_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                float* __restrict__ dW, float* __restrict__ db, int N, int I,
+                                                                int O) {
+    __shared__ float s_p[kRG][64];
+    const int f = threadIdx.x, rg = threadIdx.y, i = min((int)blockIdx.x * 64 + f, I - 1), o = blockIdx.y;
     float s = 0.0f, sb = 0.0f;
-    for (int n = 0; n < N; n++) {
+    for (int n = rg; n < N; n += kRG) {
         const float d = dY[(size_t)n * O + o];
         s += d * X[(size_t)n * I + i];
         sb += d;
     }
-    dW[(size_t)o * I + i] = s;
-    if (i == 0) db[o] = sb;
+    s = rg_sum(s, s_p, f, rg);
+    sb = rg_sum(sb, s_p, f, rg);
+    if (rg == 0 && (int)blockIdx.x * 64 + f < I) dW[(size_t)o * I + i] = s;
+    if (rg == 0 && f == 0 && blockIdx.x == 0) db[o] = sb;
 }
 
 // BCEWithLogitsLoss(pos_weight), mean over the batch (train_model.py:221,251): loss and d loss / d logit
@@ -722,9 +758,11 @@ constexpr int kMaxSplit = 512;                  // backward-weights pixel slices
 constexpr size_t kMaxPartialFloats = 96u << 20; // ... bounded by 384 MiB of partial sums
 constexpr int kBnSplit = 64;                    // BatchNorm reduction: sample chunks per channel
 
-int wgrad_split(int ntiles, size_t nw) {
+// pixel slices of a backward-weights launch: enough workgroups (slices x channel blocks) for two per CU, bounded memory
+int wgrad_split(int ntiles, size_t nw, int blocks) {
     const size_t cap = std::max<size_t>(8, kMaxPartialFloats / nw);
-    return (int)std::min<size_t>(std::min<size_t>((size_t)ntiles, (size_t)kMaxSplit), cap);
+    const size_t want = std::max<size_t>(8, (size_t)(1024 / std::max(1, blocks)));
+    return (int)std::min<size_t>(std::min<size_t>((size_t)ntiles, std::min<size_t>(want, (size_t)kMaxSplit)), cap);
 }
 // sample chunks of the BatchNorm reductions: enough workgroups to fill the chip, never more chunks than samples
 int bn_chunks(int N, int C) { return N < 64 ? 1 : std::max(1, std::min(std::min(N / 4, kBnSplit), 2048 / C)); }
@@ -873,7 +911,7 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
         A(&L.wpf, (size_t)9 * L.ci * L.co);
         A(&L.wpd, (size_t)9 * L.ci * L.co);
         max_act = std::max(max_act, std::max(full, N * L.ci * L.wi * L.wi));
-        const int tiles = wgrad_split(conv_tiles(L.wi, max_batch, 128), (size_t)9 * L.ci * L.co);
+        const int tiles = wgrad_split(conv_tiles(L.wi, max_batch, kWgTile), (size_t)9 * L.ci * L.co, (int)(cdiv(L.co, 64) * cdiv(L.ci, 64)));
         tr->partial_floats = std::max(tr->partial_floats, (size_t)tiles * 9 * L.ci * L.co);
     }
     A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX[0], max_act); A(&tr->dX[1], max_act);
@@ -1041,10 +1079,10 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
     for (int k = 3; k >= 0; k--) {
         TrainFc& f = tr->fc[k];
         const float* xin_k = k == 0 ? tr->gap : tr->fc[k - 1].y;
-        hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(f.in, 64), f.out), dim3(64), 0, s, dy, xin_k, tr->G + f.w,
+        hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(f.in, 64), f.out), dim3(64, kRG), 0, s, dy, xin_k, tr->G + f.w,
                            tr->G + f.b, N, f.in, f.out);
         float* dxk = tr->dfc[0];   // never the buffer dy lives in (dz or dfc[1]): the kernel reads all of dy per output
-        hipLaunchKernelGGL(lgt_fc_bwd_x_kernel, dim3(cdiv(f.in, 64), N), dim3(64), 0, s, dy, tr->P_ + f.w, dxk, N, f.in, f.out);
+        hipLaunchKernelGGL(lgt_fc_bwd_x_kernel, dim3(cdiv(f.in, 64), N), dim3(64, kRG), 0, s, dy, tr->P_ + f.w, dxk, N, f.in, f.out);
         if (k > 0) {
             TrainFc& p = tr->fc[k - 1];   // dxk = gradient at p.y -> through dropout / ReLU / BN1d to p.u
             float* du = tr->dfc[1];
@@ -1061,7 +1099,7 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
     hipLaunchKernelGGL(lgt_att_bwd_kernel, dim3(N), dim3(256), 0, s, last.out, tr->att_a, dy, tr->P_ + tr->att_w, spatial, F, P,
                        tr->dA[0], tr->att_part);
     if (spatial)
-        hipLaunchKernelGGL(lgt_colsum_kernel, dim3(cdiv(F + 1, 64)), dim3(64), 0, s, tr->att_part, N, F + 1, tr->G + tr->att_w);
+        hipLaunchKernelGGL(lgt_colsum_kernel, dim3(cdiv(F + 1, 64)), dim3(64, kRG), 0, s, tr->att_part, N, F + 1, tr->G + tr->att_w);
     // encoder.  Main chain per layer: BN backward (reduce, dx) -> backward-data convolution; the backward-weights
     // convolution of the layer (+ the ordered sum of its pixel slices) runs beside it on the second stream.  dX is double
     // buffered: layer li's dX is rewritten by layer li-2, which first waits for layer li's backward-weights.
@@ -1098,7 +1136,7 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
         TR_HIP(hipEventRecord(tr->ev_dx[li], s));
         TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));
         const size_t nw = (size_t)9 * L.ci * L.co;
-        const int ntiles = conv_tiles(L.wi, N, 128), Sw = wgrad_split(ntiles, nw);
+        const int ntiles = conv_tiles(L.wi, N, kWgTile), Sw = wgrad_split(ntiles, nw, (int)(cdiv(L.co, 64) * cdiv(L.ci, 64)));
         launch_wgrad(L.wi, dim3(Sw, cdiv(L.co, 64), cdiv(L.ci, 64)), sw, ain, dXl, tr->partial, N, L.ci, L.co, ntiles);
         hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, sw, tr->partial, Sw, L.ci, L.co, tr->G + L.w);
         TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
