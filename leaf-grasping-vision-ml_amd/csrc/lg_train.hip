@@ -17,7 +17,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -247,8 +250,13 @@ __global__ __launch_bounds__(256, 2) void lgt_wgrad_kernel(const float* __restri
 __global__ void lgt_wreduce_kernel(const float* __restrict__ partial, int S, int CI, int CO, float* __restrict__ gw) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x, n = 9 * CI * CO;
     if (e >= n) return;
-    float s = 0.0f;
-    for (int k = 0; k < S; k++) s += partial[(size_t)k * n + e];
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // four interleaved chains (loads in flight), combined in a fixed order
+    int k = 0;
+    for (; k + 4 <= S; k += 4)
+#pragma unroll
+        for (int u = 0; u < 4; u++) s4[u] += partial[(size_t)(k + u) * n + e];
+    for (; k < S; k++) s4[0] += partial[(size_t)k * n + e];
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
     gw[((size_t)co * CI + ci) * 9 + tap] = s;
 }
@@ -639,10 +647,14 @@ __global__ __launch_bounds__(64 * kRG) void lgt_fc_bwd_w_kernel(const float* __r
     if (rg == 0 && f == 0 && blockIdx.x == 0) db[o] = sb;
 }
 
+// hyper-parameters of a step, refreshed on the device before every step (outside the captured graph)
+struct AdamHp { float lr, beta1, beta2, eps, weight_decay, max_norm, pos_weight, pad; };
 // BCEWithLogitsLoss(pos_weight), mean over the batch (train_model.py:221,251): loss and d loss / d logit
 __global__ __launch_bounds__(256) void lgt_loss_kernel(const float* __restrict__ z, const float* __restrict__ y, int N,
-                                                       float pos_weight, float* __restrict__ loss, float* __restrict__ dz) {
+                                                       const AdamHp* __restrict__ hp, float* __restrict__ loss,
+                                                       float* __restrict__ dz) {
     __shared__ float s_red[4];
+    const float pos_weight = hp->pos_weight;
     float s = 0.0f;
     for (int n = threadIdx.x; n < N; n += 256) {
         const float zn = z[n], yn = y[n];
@@ -666,7 +678,6 @@ __global__ __launch_bounds__(256) void lgt_sumsq_kernel(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-struct AdamHp { float lr, beta1, beta2, eps, weight_decay, max_norm; };
 
 // state[0] = step count (float), state[1] = total gradient norm of this step (before clipping).  One wave adds the
 // partial sums in index order and advances the step count when the optimizer runs.
@@ -700,7 +711,9 @@ __global__ __launch_bounds__(256) void lgt_adam_kernel(float* __restrict__ p, co
 
 // keep masks of all dropout layers in one launch: 0 or 1/(1-p); counter-based hash of (seed, index)
 struct MaskTable { size_t end[8]; float p[8]; int n; };
-__global__ void lgt_mask_kernel(float* __restrict__ mask, MaskTable T, uint64_t seed) {
+__global__ void lgt_mask_kernel(float* __restrict__ mask, MaskTable T, const uint64_t* __restrict__ seed_,
+                                const float* __restrict__ state) {
+    const uint64_t seed = seed_[0] * 0x100000001B3ull + 0x51ull * (uint64_t)state[0];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int l = 0;
     while (l < T.n && i >= T.end[l]) l++;
@@ -746,6 +759,9 @@ struct lg_trainer {
     AdamHp* hp = nullptr;
     hipStream_t stream = nullptr, stream_w = nullptr;   // main chain; backward-weights branch
     hipEvent_t ev_dx[8] = {}, ev_wg[8] = {};
+    uint64_t* seed_dev = nullptr;
+    bool use_graph = false;                      // LG_TRAIN_GRAPH=1: replay the step as a captured graph (measured: no gain)
+    std::map<uint64_t, hipGraphExec_t> graphs;   // key: N, masks drawn on the device, optimizer applied
     int64_t steps = 0;
     std::string err;
     std::vector<void*> allocs;
@@ -920,9 +936,12 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     A(&tr->dfc[0], N * F); A(&tr->dfc[1], N * F); A(&tr->logits, N); A(&tr->dz, N);
     for (int k = 0; k < 4; k++) { A(&tr->fc[k].u, N * tr->fc[k].out); if (k < 3) A(&tr->fc[k].y, N * tr->fc[k].out); }
     A(&tr->loss, 4); A(&tr->state, 4); A(&tr->norm_part, kNormParts);
-    float* hp = nullptr;
+    float *hp = nullptr, *sd = nullptr;
     A(&hp, sizeof(AdamHp) / sizeof(float));
     tr->hp = (AdamHp*)hp;
+    A(&sd, 2);
+    tr->seed_dev = (uint64_t*)sd;
+    if (const char* e = getenv("LG_TRAIN_GRAPH")) tr->use_graph = atoi(e) != 0;
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream_w, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     for (int k = 0; k < 8 && rc == LG_OK; k++)
@@ -944,6 +963,7 @@ int lg_train_destroy(lg_trainer* tr) {
     if (!tr) return LG_ERR_INVALID;
     hipSetDevice(tr->device);
     hipDeviceSynchronize();
+    for (auto& kv : tr->graphs) hipGraphExecDestroy(kv.second);
     if (tr->stream) hipStreamDestroy(tr->stream);
     if (tr->stream_w) hipStreamDestroy(tr->stream_w);
     for (int k = 0; k < 8; k++) {
@@ -996,32 +1016,19 @@ int lg_train_get_state(lg_trainer* tr, float* params, float* buffers, float* exp
     return LG_OK;
 }
 
-// One optimisation step on N samples.  x [N][9][32][32], labels [N] (0/1) and masks (NULL, or [N][mask_row] keep masks
-// already scaled by 1/(1-p)) are DEVICE pointers; hp is a host struct.  apply_update = 0 computes loss and gradients only.
-int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, const float* masks, uint64_t seed,
-                  const lg_train_hparams* hp, int apply_update, float* loss_host, float* grad_norm_host,
-                  float* logits_dev) {
-    if (!tr || !x || !labels || !hp) return LG_ERR_INVALID;
-    if (N < 2 || N > tr->capN) { tr->err = "lg_train_step: N must be in [2, max_batch] (BatchNorm needs a batch)"; return LG_ERR_INVALID; }
-    hipSetDevice(tr->device);
+// Everything of a step whose launch parameters depend only on (N, draw_masks, apply_update): captured into a graph.
+static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update) {
     hipStream_t s = tr->stream;
     const int F = tr->F, P = tr->P;
     const float eps = 1e-5f, mom = 0.1f;
-    TR_HIP(hipMemcpyAsync(tr->xin, x, (size_t)N * 9 * 1024 * 4, hipMemcpyDeviceToDevice, s));
-    TR_HIP(hipMemcpyAsync(tr->labels, labels, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
-    const AdamHp h = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->max_grad_norm};
-    TR_HIP(hipMemcpyAsync(tr->hp, &h, sizeof(h), hipMemcpyHostToDevice, s));
     const size_t mrow = tr->mask_row;
-    // masks are stored layer-major: layer block [N][width] at offset N * (row offset of the layer)
-    if (masks) {
-        TR_HIP(hipMemcpyAsync(tr->masks, masks, (size_t)N * mrow * 4, hipMemcpyDeviceToDevice, s));
-    } else {
+    if (draw_masks) {
         MaskTable mt = {};
         for (auto& L : tr->layers)
             if (L.pool) { mt.end[mt.n] = (size_t)N * (L.mask + L.co); mt.p[mt.n++] = tr->drop2d_p; }
         for (int k = 0; k < 3; k++) { mt.end[mt.n] = (size_t)N * (tr->fc[k].mask + tr->fc[k].out); mt.p[mt.n++] = tr->drop_p[k]; }
         hipLaunchKernelGGL(lgt_mask_kernel, dim3(cdiv((size_t)N * mrow, 256)), dim3(256), 0, s, tr->masks, mt,
-                           seed * 0x100000001B3ull + 0x51ull * (uint64_t)tr->steps);
+                           (const uint64_t*)tr->seed_dev, (const float*)tr->state);
     }
     TR_HIP(hipMemsetAsync(tr->G, 0, tr->n_params * 4, s));   // conv biases: exact zero gradient (see DESIGN)
     {
@@ -1072,7 +1079,7 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
             fin = f.y;
         }
     }
-    hipLaunchKernelGGL(lgt_loss_kernel, dim3(1), dim3(256), 0, s, tr->logits, tr->labels, N, hp->pos_weight, tr->loss, tr->dz);
+    hipLaunchKernelGGL(lgt_loss_kernel, dim3(1), dim3(256), 0, s, tr->logits, tr->labels, N, (const AdamHp*)tr->hp, tr->loss, tr->dz);
 
     // ---------------- backward: classifier
     const float* dy = tr->dz;
@@ -1149,13 +1156,59 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
     // ---------------- optimizer
     hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
     hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(1), 0, s, tr->norm_part, kNormParts, apply_update ? 1 : 0, tr->state);
-    if (apply_update) {
+    if (apply_update)
         hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
                            tr->n_params, tr->hp, tr->state);
-        tr->steps++;
-    }
-    if (logits_dev) TR_HIP(hipMemcpyAsync(logits_dev, tr->logits, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
     TR_HIP(hipGetLastError());
+    return LG_OK;
+}
+
+// One optimisation step on N samples.  x [N][9][32][32], labels [N] (0/1) and masks (NULL, or [N][mask_row] keep masks
+// already scaled by 1/(1-p)) are DEVICE pointers; hp is a host struct.  apply_update = 0 computes loss and gradients only.
+int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, const float* masks, uint64_t seed,
+                  const lg_train_hparams* hp, int apply_update, float* loss_host, float* grad_norm_host,
+                  float* logits_dev) {
+    if (!tr || !x || !labels || !hp) return LG_ERR_INVALID;
+    if (N < 2 || N > tr->capN) { tr->err = "lg_train_step: N must be in [2, max_batch] (BatchNorm needs a batch)"; return LG_ERR_INVALID; }
+    hipSetDevice(tr->device);
+    hipStream_t s = tr->stream;
+    TR_HIP(hipMemcpyAsync(tr->xin, x, (size_t)N * 9 * 1024 * 4, hipMemcpyDeviceToDevice, s));
+    TR_HIP(hipMemcpyAsync(tr->labels, labels, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    const AdamHp h = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->max_grad_norm, hp->pos_weight, 0.0f};
+    TR_HIP(hipMemcpyAsync(tr->hp, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    TR_HIP(hipMemcpyAsync(tr->seed_dev, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
+    if (masks) TR_HIP(hipMemcpyAsync(tr->masks, masks, (size_t)N * tr->mask_row * 4, hipMemcpyDeviceToDevice, s));
+    const uint64_t key = (uint64_t)N | ((uint64_t)(masks ? 0 : 1) << 32) | ((uint64_t)(apply_update ? 1 : 0) << 33);
+    bool launched = false;
+    if (tr->use_graph) {
+        auto it = tr->graphs.find(key);
+        if (it == tr->graphs.end()) {
+            // ~75 short launches on two streams captured once per (N, mask source, update) and replayed
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = enqueue_step(tr, N, masks == nullptr, apply_update);
+                const hipError_t ee = hipStreamEndCapture(s, &g);
+                if (rc == LG_OK && ee == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess)
+                    it = tr->graphs.emplace(key, ge).first;
+                if (g) hipGraphDestroy(g);
+            }
+            if (it == tr->graphs.end()) {
+                (void)hipGetLastError();
+                tr->use_graph = false;   // capture not available: plain launches from here on
+            }
+        }
+        if (it != tr->graphs.end()) {
+            TR_HIP(hipGraphLaunch(it->second, s));
+            launched = true;
+        }
+    }
+    if (!launched) {
+        const int rc = enqueue_step(tr, N, masks == nullptr, apply_update);
+        if (rc != LG_OK) return rc;
+    }
+    if (apply_update) tr->steps++;
+    if (logits_dev) TR_HIP(hipMemcpyAsync(logits_dev, tr->logits, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
     if (loss_host || grad_norm_host) {
         float l = 0.f, st[4] = {0.f, 0.f, 0.f, 0.f};
         TR_HIP(hipMemcpyAsync(&l, tr->loss, 4, hipMemcpyDeviceToHost, s));

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--filters", default="64,128,256")
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="also time the same step written with torch.nn modules + torch.optim.Adam on the same device "
+                         "(PyTorch-ROCm eager: MIOpen / rocBLAS kernels) -- what the reference's script would run here")
     a = ap.parse_args()
     filters = tuple(int(v) for v in a.filters.split(","))
     dev = torch.device("cuda:0")
@@ -66,6 +69,57 @@ def main():
                           "samples_per_s": round(n / dt, 1), "conv_tflops": round(fl / dt / 1e12, 2),
                           "loss_first": round(first, 4), "loss_last": round(loss.value, 4)}), flush=True)
         del tr
+        if a.torch_baseline:
+            print(json.dumps(torch_eager(n, filters, x, y, a.steps, a.warmup)), flush=True)
+
+
+def torch_eager(n, filters, x, y, steps, warmup):
+    """The architecture of scripts/utils/ml_grasp_optimizer/model.py (spatial attention) and the loop body of
+    scripts/train_model.py:247-265, written here with stock torch modules (measurement only)."""
+    import torch.nn as nn
+    blocks, c = [], 9
+    for f in filters:
+        blocks.append(nn.Sequential(nn.Conv2d(c, f, 3, padding=1), nn.BatchNorm2d(f), nn.ReLU(inplace=True),
+                                    nn.Conv2d(f, f, 3, padding=1), nn.BatchNorm2d(f), nn.ReLU(inplace=True),
+                                    nn.MaxPool2d(2), nn.Dropout2d(0.3)))
+        c = f
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.ModuleList(blocks)
+            self.attention = nn.Sequential(nn.Conv2d(c, 1, 1), nn.Sigmoid())
+            self.classifier = nn.Sequential(nn.Linear(c, c), nn.BatchNorm1d(c), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                                            nn.Linear(c, c // 2), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                                            nn.Linear(c // 2, c // 4), nn.BatchNorm1d(c // 4), nn.ReLU(inplace=True), nn.Dropout(0.4),
+                                            nn.Linear(c // 4, 1))
+
+        def forward(self, h):
+            for b in self.encoder:
+                h = b(h)
+            h = h * self.attention(h)
+            return self.classifier(h.mean(dim=(2, 3)))
+
+    net = Net().to(x.device).train()
+    crit = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([2.0], device=x.device))
+    opt = torch.optim.Adam(net.parameters(), lr=0.0005, weight_decay=0.01)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(net(x).squeeze(1), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1.0)
+        opt.step()
+        return loss
+    for _ in range(warmup + 3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    loss.item()
+    dt = (time.perf_counter() - t0) / steps
+    return {"torch_eager_batch": n, "ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(n / dt, 1)}
 
 
 if __name__ == "__main__":
