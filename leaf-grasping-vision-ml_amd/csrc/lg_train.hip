@@ -72,26 +72,27 @@ __device__ inline float rg_sum(float v, float (*s)[64], int f, int rg) {
 
 // ------------------------------------------------------------------------------------------------ conv fwd / dgrad
 // out[n][co][y][x] = bias[co] + sum_{tap,ci} wp[tap][ci][co] * in[n][ci][y+ky-1][x+kx-1]     (zero padding)
-// Workgroup = 4 waves = WPX x (4 / WPX) waves over (pixels, output channels); a wave owns PB x CB blocks of 32 pixels x 32
-// channels.  Two shapes, 64 output channels per workgroup in both:
-//   <PB 2, CB 2, WPX 4>  256 pixels per workgroup, 4 MFMAs per 4 LDS operand reads  -- large batches
-//   <PB 1, CB 1, WPX 2>   64 pixels per workgroup, 4x the workgroups                 -- small batches (the reference
-//                                                  trains with 16 samples: a 8x8 layer has 1024 pixels in total)
-template <int WI, int PB, int CB, int WPX, int KC>
+// Workgroup = 4 waves = WPX x WCO x KS waves over (pixels, output channels, slices of the staged input channels); a wave
+// owns PB x CB blocks of 32 pixels x 32 channels.  Three shapes:
+//   <PB 2, CB 2, WPX 4, KS 1>  256 pixels x 64 channels, 4 MFMAs per 4 LDS operand reads   -- large batches
+//   <PB 1, CB 1, WPX 2, KS 1>   64 pixels x 64 channels, 4x the workgroups                  -- small batches
+//   <PB 1, CB 1, WPX 1, KS 4>   32 pixels x 32 channels, the four waves split K             -- the reference's batch of 16,
+//                                where a 8x8 layer has 1024 pixels in total: 256 workgroups instead of 16
+template <int WI, int PB, int CB, int WPX, int KS, int KC>
 __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
                                                        int CI, int CO) {
-    constexpr int WCO = 4 / WPX, TILE = 32 * PB * WPX;
-    static_assert(32 * CB * WCO == 64, "64 output channels per workgroup");
+    constexpr int WCO = 4 / (WPX * KS), TILE = 32 * PB * WPX, COT = 32 * CB * WCO, KCT = KC * KS;
+    static_assert(WPX * WCO * KS == 4, "4 waves");
     using T = Tile<WI, TILE>;
-    constexpr int IN_ELEMS = KC * T::PLANE, NIN = (IN_ELEMS + 255) / 256, IN_PAD = NIN * 256;
-    constexpr int W4_ELEMS = 9 * KC * 16, NW4 = (W4_ELEMS + 255) / 256;
+    constexpr int IN_ELEMS = KCT * T::PLANE, NIN = (IN_ELEMS + 255) / 256, IN_PAD = NIN * 256;
+    constexpr int W4_ELEMS = 9 * KCT * (COT / 4), NW4 = (W4_ELEMS + 255) / 256;
     constexpr int BUF = IN_PAD + NW4 * 1024;   // floats per stage
     // one shared object, two stages of [input halo tile | weights], both filled by global_load_lds in load order
     __shared__ __attribute__((aligned(16))) float s_buf[2 * BUF];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
-    const int wpx = wave % WPX, wco = wave / WPX;
-    const int tile = blockIdx.x, n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR, co0 = blockIdx.y * 64;
+    const int wpx = wave % WPX, wco = (wave / WPX) % WCO, ks = wave / (WPX * WCO);
+    const int tile = blockIdx.x, n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR, co0 = blockIdx.y * COT;
 
     f32x16 acc[PB][CB];
 #pragma unroll
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int j = 0; j < NW4; j++) {
-        const int idx = t + 256 * j, q = idx & 15, rest = idx >> 4, ci = rest % KC, tap = rest / KC;
+        const int idx = t + 256 * j, q = idx % (COT / 4), rest = idx / (COT / 4), ci = rest % KCT, tap = rest / KCT;
         off_w[j] = (idx < W4_ELEMS && co0 + 4 * q < CO) ? (tap * CI + ci) * CO + co0 + 4 * q : -1;
         ci_w[j] = ci;
     }
@@ -146,9 +147,9 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
     };
     issue_chunk(0, 0);
     int stage = 0;
-    for (int c0 = 0; c0 < CI; c0 += KC, stage ^= 1) {
+    for (int c0 = 0; c0 < CI; c0 += KCT, stage ^= 1) {
         __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
-        if (c0 + KC < CI) issue_chunk(c0 + KC, stage ^ 1);
+        if (c0 + KCT < CI) issue_chunk(c0 + KCT, stage ^ 1);
         const float* s_in = s_buf + stage * BUF;
         const float* s_w = s_in + IN_PAD;
 #pragma unroll
@@ -156,10 +157,10 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int k0 = 0; k0 < KC; k0 += 2) {
-                const int ci = k0 + kh;
+                const int ci = ks * KC + k0 + kh;   // the wave's slice of the staged channels
                 float a[CB], b[PB];
 #pragma unroll
-                for (int j = 0; j < CB; j++) a[j] = s_w[(tap * KC + ci) * 64 + aoff + 32 * j];
+                for (int j = 0; j < CB; j++) a[j] = s_w[(tap * KCT + ci) * COT + aoff + 32 * j];
 #pragma unroll
                 for (int i = 0; i < PB; i++) b[i] = s_in[ci * T::PLANE + boff[i] + ky * T::TW + kx];
 #pragma unroll
@@ -168,6 +169,19 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
                     for (int j = 0; j < CB; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[i], acc[i][j], 0, 0, 0);
             }
         }
+    }
+    if (KS > 1) {   // the K slices of a tile are added in slice order by the slice-0 wave
+        static_assert(KS == 1 || (PB == 1 && CB == 1 && WPX == 1), "K split: one 32 x 32 tile per workgroup");
+        __syncthreads();
+        if (ks > 0)
+#pragma unroll
+            for (int r = 0; r < 16; r++) s_buf[(ks - 1) * 1024 + r * 64 + lane] = acc[0][0][r];
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; k++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[0][0][r] += s_buf[k * 1024 + r * 64 + lane];
     }
 #pragma unroll
     for (int i = 0; i < PB; i++) {
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
                                                                 const float* __restrict__ gam, const float* __restrict__ bet,
                                                                 const float* __restrict__ dmask, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ part, int chunk,
-                                                                int N, int C, int WI) {
+                                                                float* __restrict__ dx, int N, int C, int WI) {
     __shared__ float s_red[4];
     const int c = blockIdx.x, t = threadIdx.x;
     const int na = blockIdx.y * chunk, nb = min(N, na + chunk);
@@ -423,6 +437,32 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
         else {   // part[0..C) rows = dgamma chunks, part[C..2C) rows = dbeta chunks; summed by lgt_rowsum_kernel
             part[(size_t)c * gridDim.y + blockIdx.y] = sg;
             part[(size_t)(C + c) * gridDim.y + blockIdx.y] = sb;
+        }
+    }
+    if (dx == nullptr || gridDim.y != 1) return;
+    // small batches: the same workgroup writes dx of its channel (what lgt_bn_bwd_dx_kernel does for large ones)
+    const float invM = 1.0f / (float)(N * WI * WI), mb = sb * invM, mg = sg * invM;
+    if (!POOL) {
+        const int HW = WI * WI, M = N * HW;
+        for (int i = t; i < M; i += 256) {
+            const size_t e = ((size_t)(i / HW) * C + c) * HW + i % HW;
+            const float xh = (x[e] - mu) * rs;
+            const float dy = (xh * g + b > 0.0f) ? dout[e] : 0.0f;
+            dx[e] = g * rs * (dy - mb - xh * mg);
+        }
+    } else {
+        const int WO = WI / 2, HWO = WO * WO, M = N * HWO;
+        for (int i = t; i < M; i += 256) {
+            const int n = i / HWO, r = i % HWO, yo = r / WO, xo = r % WO;
+            const size_t nc = (size_t)n * C + c, e0 = (nc * WI + 2 * yo) * WI + 2 * xo;
+            const float xh[4] = {(x[e0] - mu) * rs, (x[e0 + 1] - mu) * rs, (x[e0 + WI] - mu) * rs, (x[e0 + WI + 1] - mu) * rs};
+            const float y[4] = {fmaxf(xh[0] * g + b, 0.0f), fmaxf(xh[1] * g + b, 0.0f), fmaxf(xh[2] * g + b, 0.0f),
+                                fmaxf(xh[3] * g + b, 0.0f)};
+            const int k = argmax4(y);
+            const float dyk = y[k] > 0.0f ? dout[nc * HWO + r] * dmask[nc] : 0.0f;
+            const size_t eo[4] = {e0, e0 + 1, e0 + WI, e0 + WI + 1};
+#pragma unroll
+            for (int q = 0; q < 4; q++) dx[eo[q]] = g * rs * ((q == k ? dyk : 0.0f) - mb - xh[q] * mg);
         }
     }
 }
@@ -546,18 +586,25 @@ __global__ __launch_bounds__(64 * kRG) void lgt_colsum_kernel(const float* __res
     if (rg == 0 && (int)blockIdx.x * 64 + f < K) out[k] = s;
 }
 
-// Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples)
+// Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples), the weight row held in registers (I <= 1024)
 __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ Y, int N, int I,
                                                          int O) {
     const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= O) return;
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = lane + 64 * k < I ? W[(size_t)o * I + lane + 64 * k] : 0.0f;
+    const float bo = b[o];
+    const int nk = (I + 63) / 64;
     for (int n = blockIdx.y * 16; n < min(N, (int)blockIdx.y * 16 + 16); n++) {
         float s = 0.0f;
-        for (int i = lane; i < I; i += 64) s += X[(size_t)n * I + i] * W[(size_t)o * I + i];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nk) s += (lane + 64 * k < I ? X[(size_t)n * I + lane + 64 * k] : 0.0f) * w[k];
 #pragma unroll
         for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
-        if (lane == 0) Y[(size_t)n * O + o] = s + b[o];
+        if (lane == 0) Y[(size_t)n * O + o] = s + bo;
     }
 }
 
@@ -803,20 +850,24 @@ int dalloc(lg_trainer* tr, float** p, size_t floats) {
     return LG_OK;
 }
 
-// workgroups of the large-tile shape below which the small-tile shape is launched (256 CUs x 2 resident workgroups)
-constexpr int kSmallConvBelow = 512;
+// workgroups of a shape below which the next smaller shape is launched
+constexpr int kSmallConvBelow = 512, kSplitConvBelow = 256;
 int conv_tiles(int wi, int N, int tile);
 void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N, int CI,
                  int CO) {
-    const unsigned cb = (unsigned)((CO + 63) / 64);
+    const unsigned cb = (unsigned)((CO + 63) / 64), cb32 = (unsigned)((CO + 31) / 32);
     const bool small = conv_tiles(wi, N, 256) * (int)cb < kSmallConvBelow;
+    const bool split = conv_tiles(wi, N, 64) * (int)cb < kSplitConvBelow && CI >= 32;
 #define LGT_CONV(W)                                                                                                    \
-    if (small)                                                                                                         \
-        hipLaunchKernelGGL((lgt_conv_kernel<W, 1, 1, 2, 16>), dim3(conv_tiles(W, N, 64), cb), dim3(256), 0, s, in, wp, bias, \
-                           out, N, CI, CO);                                                                            \
+    if (split)                                                                                                         \
+        hipLaunchKernelGGL((lgt_conv_kernel<W, 1, 1, 1, 4, 8>), dim3(conv_tiles(W, N, 32), cb32), dim3(256), 0, s, in, wp,  \
+                           bias, out, N, CI, CO);                                                                      \
+    else if (small)                                                                                                    \
+        hipLaunchKernelGGL((lgt_conv_kernel<W, 1, 1, 2, 1, 16>), dim3(conv_tiles(W, N, 64), cb), dim3(256), 0, s, in, wp,   \
+                           bias, out, N, CI, CO);                                                                      \
     else                                                                                                               \
-        hipLaunchKernelGGL((lgt_conv_kernel<W, 2, 2, 4, 8>), dim3(conv_tiles(W, N, 256), cb), dim3(256), 0, s, in, wp, bias, \
-                           out, N, CI, CO);
+        hipLaunchKernelGGL((lgt_conv_kernel<W, 2, 2, 4, 1, 8>), dim3(conv_tiles(W, N, 256), cb), dim3(256), 0, s, in, wp,   \
+                           bias, out, N, CI, CO);
     switch (wi) {
         case 32: LGT_CONV(32) break;
         case 16: LGT_CONV(16) break;
@@ -1123,22 +1174,23 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         const int S = bn_chunks(N, L.co), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         if (L.pool) {
             hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, N, L.co, L.wi);
+                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, dXl, N, L.co, L.wi);
         } else {
             hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<false>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, N, L.co, L.wi);
+                               tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, dXl, N, L.co, L.wi);
         }
-        if (Sy > 1)
+        if (Sy > 1) {   // large batches: ordered sum of the chunks, then dx over the whole chip
             hipLaunchKernelGGL(lgt_rowsum_kernel, dim3(cdiv(2 * L.co, 64)), dim3(64), 0, s, tr->bn_part, 2 * L.co, Sy, tr->G + L.g,
                                tr->G + L.be, L.co);
-        if (L.pool) {
-            const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
-            hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
-        } else {
-            const size_t n = (size_t)N * L.co * L.wi * L.wi;
-            hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
-                               tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
+            if (L.pool) {
+                const size_t n = (size_t)N * L.co * L.wi * L.wi / 4;
+                hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be,
+                                   dm, tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
+            } else {
+                const size_t n = (size_t)N * L.co * L.wi * L.wi;
+                hipLaunchKernelGGL(lgt_bn_bwd_dx_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be,
+                                   dm, tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
+            }
         }
         TR_HIP(hipEventRecord(tr->ev_dx[li], s));
         TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));

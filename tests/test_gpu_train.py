@@ -102,16 +102,18 @@ def test_train_step_matches_reference_fixture(att, filt, n):
 
 
 @pytest.mark.parametrize("att,filt,n,seed", [("spatial", (64, 128, 256), 16, 1), ("none", (64, 128, 256, 512), 8, 2),
-                                             ("spatial", (128, 256, 512), 5, 3), ("spatial", (32, 64, 128), 16, 4)])
+                                             ("spatial", (128, 256, 512), 5, 3), ("spatial", (32, 64, 128), 16, 4),
+                                             ("spatial", (64, 128, 256), 128, 5)])
 def test_train_step_with_dropout_masks_vs_oracle(att, filt, n, seed):
-    """The reference's batch size (16) and every encoder_filters configuration of its sweep, with random Dropout2d /
+    """The reference's batch size (16) and every encoder_filters configuration of its sweep, plus a batch of 128 (the
+    large-tile convolution shape, BatchNorm reductions split over sample chunks), with random Dropout2d /
     Dropout keep masks handed to both sides; first step from the closed-form weights and a second step from the ORACLE's
     state after the first (parameters, running statistics, Adam moments, step count loaded into the trainer)."""
     params = S.cnn_closed_form_params(seed=seed, attention_type=att, filters=filt)
     x = S.synthetic_patches(n, seed=20 + seed)
     y = (np.random.default_rng(seed).random(n) < 0.4).astype(np.float32)
     y[0], y[1] = 0.0, 1.0
-    tr = make_trainer(att, filt, 16)
+    tr = make_trainer(att, filt, max(16, n))
     tr.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     mk = random_masks(filt, n, seed)
     ref = O.cnn_train_step(params, x, y, masks=mk)
