@@ -327,7 +327,7 @@ def main():
         if world == 1 and args.train_steps > 0 and not args.no_cnn:
             # secondary figure (never `value`): SURVEY 8f row 4, the inner loop body of scripts/train_model.py:247-265
             try:
-                import ctypes as C
+                import ctypes as _C
                 from leafgrasp_amd._lib import lib as _lib
                 from leafgrasp_amd.trainer import GraspTrainer
                 ts = {}
@@ -336,11 +336,11 @@ def main():
                     base = torch.from_numpy(SI.synthetic_patches(256, seed=1)).to(dev)
                     xb = base.repeat((nb + 255) // 256, 1, 1, 1)[:nb].contiguous()
                     yb = (torch.arange(nb, device=dev) % 3 == 0).float()
-                    loss = C.c_float()
+                    loss = _C.c_float()
 
                     def one(sync):
-                        rc = _lib.lg_train_step(tr._h, xb.data_ptr(), yb.data_ptr(), nb, None, 1, C.byref(tr.hp), 1,
-                                                C.byref(loss) if sync else None, None, None)
+                        rc = _lib.lg_train_step(tr._h, xb.data_ptr(), yb.data_ptr(), nb, None, 1, _C.byref(tr.hp), 1,
+                                                _C.byref(loss) if sync else None, None, None)
                         if rc != 0:
                             raise RuntimeError(_lib.lg_train_last_error(tr._h).decode())
                     torch.cuda.synchronize(dev)

@@ -224,7 +224,7 @@ int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]);
 /* ---- GraspPointCNN training step: one call = one iteration of the inner loop of
    scripts/train_model.py:247-265 (zero_grad, forward in train mode, BCEWithLogitsLoss(pos_weight), backward,
    clip_grad_norm_(max_grad_norm), Adam step with L2 weight_decay) on the model of
-   scripts/utils/ml_grasp_optimizer/model.py:5-128 with attention LG_ATT_SPATIAL (the script's model) or LG_ATT_NONE.
+   scripts/utils/ml_grasp_optimizer/model.py:5-128 with any LG_ATT_* attention (LG_ATT_SPATIAL = the script's model).
    Flat parameter vector = model.parameters() order; flat buffer vector = running_mean, running_var of every BatchNorm
    in module order.  Dropout keep masks: one [N][width] block per dropout layer, concatenated in module order
    (Dropout2d of every encoder block: width = filters[b]; classifier Dropout 0.5 / 0.5 / 0.4: widths F, F/2, F/4),

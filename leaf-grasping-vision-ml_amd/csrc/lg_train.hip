@@ -1,7 +1,7 @@
 // GraspPointCNN training step on gfx950: forward in train mode (batch-statistics BatchNorm, Dropout2d / Dropout with
 // explicit keep masks), BCEWithLogits(pos_weight) loss, backward, global-norm gradient clipping and Adam with L2 weight
 // decay -- one call = one iteration of the inner loop of scripts/train_model.py:247-265 on the model of
-// scripts/utils/ml_grasp_optimizer/model.py:5-128 (attention 'spatial' = the script's default, or 'none';
+// scripts/utils/ml_grasp_optimizer/model.py:5-128 (every attention type -- 'spatial' is the script's default --,
 // any encoder_filters of the reference's sweep).
 //
 // Convolutions (forward, backward-data, backward-weights) run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void lgt_att_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void lgt_att_bwd_kernel(const float* __restrict__ h, const float* __restrict__ a,
                                                           const float* __restrict__ dg, const float* __restrict__ wa,
                                                           int spatial, int F, int P, float* __restrict__ dh,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, const float* __restrict__ dm) {
     __shared__ float s_a[64], s_ds[64], s_p[256];
     const int n = blockIdx.x, t = threadIdx.x;
     const float* hn = h + (size_t)n * F * P;
@@ -562,9 +562,10 @@ __global__ __launch_bounds__(256) void lgt_att_bwd_kernel(const float* __restric
     __syncthreads();
     for (int c = t; c < F; c += 256) {
         const float d = dgn[c] / (float)P, w = spatial ? wa[c] : 0.0f;
+        const float dmc = dm ? dm[(size_t)n * F + c] / (float)P : 0.0f;   // channel attention's path through mean_p h
         float pw = 0.0f;
         for (int q = 0; q < P; q++) {
-            dh[((size_t)n * F + c) * P + q] = d * s_a[q] + s_ds[q] * w;
+            dh[((size_t)n * F + c) * P + q] = d * s_a[q] + s_ds[q] * w + dmc;
             pw += s_ds[q] * hn[c * P + q];
         }
         if (spatial) part[(size_t)n * (F + 1) + c] = pw;
@@ -584,6 +585,38 @@ __global__ __launch_bounds__(64 * kRG) void lgt_colsum_kernel(const float* __res
     for (int n = rg; n < N; n += kRG) s += part[(size_t)n * K + k];
     s = rg_sum(s, s_p, f, rg);
     if (rg == 0 && (int)blockIdx.x * 64 + f < K) out[k] = s;
+}
+
+// Channel attention (model.py:37-44, 52-58): ca = sigmoid(W2 relu(W1 m + b1) + b2) with m = mean_p h; pooled feature
+// g2 = ca * gs, gs = the (spatially attended, for 'hybrid') mean.  The two 1x1 convolutions run as the classifier's Linear
+// kernels on [N][F] / [N][F/16]; these are the elementwise pieces.
+__global__ void lgt_relu_kernel(const float* __restrict__ z, float* __restrict__ r, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = fmaxf(z[i], 0.0f);
+}
+__global__ void lgt_catt_gate_kernel(const float* __restrict__ z2, const float* __restrict__ gs, float* __restrict__ ca,
+                                     float* __restrict__ g2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = 1.0f / (1.0f + expf(-z2[i]));
+    ca[i] = c;
+    g2[i] = c * gs[i];
+}
+// dgs = dg2 * ca, dz2 = dg2 * gs * ca (1 - ca)
+__global__ void lgt_catt_gate_bwd_kernel(const float* __restrict__ dg2, const float* __restrict__ ca,
+                                         const float* __restrict__ gs, float* __restrict__ dgs, float* __restrict__ dz2,
+                                         size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = ca[i], d = dg2[i];
+    dgs[i] = d * c;
+    dz2[i] = d * gs[i] * c * (1.0f - c);
+}
+// dz1 = dr * (z1 > 0)
+__global__ void lgt_relu_bwd_kernel(const float* __restrict__ dr, const float* __restrict__ z1, float* __restrict__ dz1,
+                                    size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dz1[i] = z1[i] > 0.0f ? dr[i] : 0.0f;
 }
 
 // Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples), the weight row held in registers (I <= 1024)
@@ -793,7 +826,10 @@ struct lg_trainer {
     int filters[4] = {64, 128, 256, 0};
     std::vector<TrainLayer> layers;
     TrainFc fc[4];
-    size_t att_w = 0, att_b = 0;
+    size_t att_w = 0, att_b = 0, ca_w1 = 0, ca_b1 = 0, ca_w2 = 0, ca_b2 = 0;
+    int hid = 0;                                  // channel attention bottleneck: F / 16
+    float *ca_m = nullptr, *ca_z1 = nullptr, *ca_r = nullptr, *ca_z2 = nullptr, *ca_ca = nullptr, *gap2 = nullptr;
+    float *ca_dgs = nullptr, *ca_dz2 = nullptr, *ca_dr = nullptr, *ca_dz1 = nullptr, *ca_dm = nullptr, *ca_a1 = nullptr;
     size_t n_params = 0, n_buffers = 0, n_stats = 0, mask_row = 0;
     float drop2d_p = 0.3f, drop_p[3] = {0.5f, 0.5f, 0.4f};
     size_t mask_fc[3] = {0, 0, 0};
@@ -899,7 +935,7 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     if (!out) return LG_ERR_INVALID;
     *out = nullptr;
     if (!filters || n_blocks < 1 || n_blocks > 4 || max_batch < 2 || max_batch > 8192) return LG_ERR_INVALID;
-    if (attention_type != LG_ATT_SPATIAL && attention_type != LG_ATT_NONE) return LG_ERR_UNSUPPORTED;
+    if (attention_type < LG_ATT_SPATIAL || attention_type > LG_ATT_NONE) return LG_ERR_UNSUPPORTED;
     for (int b = 0; b < n_blocks; b++)
         if (filters[b] < 32 || filters[b] % 32 != 0 || filters[b] > 1024) return LG_ERR_INVALID;
     if (filters[n_blocks - 1] % 4 != 0) return LG_ERR_INVALID;
@@ -940,9 +976,20 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     const int F = c;
     tr->F = F;
     tr->P = wi * wi;
-    if (attention_type == LG_ATT_SPATIAL) {
+    if (filters[n_blocks - 1] % 16 != 0 && (attention_type == LG_ATT_CHANNEL || attention_type == LG_ATT_HYBRID)) {
+        delete tr;
+        return LG_ERR_INVALID;
+    }
+    if (attention_type == LG_ATT_SPATIAL || attention_type == LG_ATT_HYBRID) {   // attention.0 / spatial_attention.0
         tr->att_w = po; po += F;
         tr->att_b = po; po += 1;
+    }
+    if (attention_type == LG_ATT_CHANNEL || attention_type == LG_ATT_HYBRID) {   // attention.{1,3} / channel_attention.{1,3}
+        tr->hid = F / 16;
+        tr->ca_w1 = po; po += (size_t)tr->hid * F;
+        tr->ca_b1 = po; po += tr->hid;
+        tr->ca_w2 = po; po += (size_t)F * tr->hid;
+        tr->ca_b2 = po; po += F;
     }
     const int fin[4] = {F, F, F / 2, F / 4}, fout[4] = {F, F / 2, F / 4, 1};
     for (int k = 0; k < 4; k++) {
@@ -984,6 +1031,11 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX[0], max_act); A(&tr->dX[1], max_act);
     A(&tr->partial, tr->partial_floats); A(&tr->bn_part, (size_t)1024 * kBnSplit * 3);
     A(&tr->att_a, N * tr->P); A(&tr->gap, N * F); A(&tr->att_part, N * (F + 1));
+    if (tr->hid) {
+        A(&tr->ca_m, N * F); A(&tr->ca_z1, N * tr->hid); A(&tr->ca_r, N * tr->hid); A(&tr->ca_z2, N * F); A(&tr->ca_ca, N * F);
+        A(&tr->gap2, N * F); A(&tr->ca_dgs, N * F); A(&tr->ca_dz2, N * F); A(&tr->ca_dr, N * tr->hid); A(&tr->ca_dz1, N * tr->hid);
+        A(&tr->ca_dm, N * F); A(&tr->ca_a1, N * tr->P);
+    }
     A(&tr->dfc[0], N * F); A(&tr->dfc[1], N * F); A(&tr->logits, N); A(&tr->dz, N);
     for (int k = 0; k < 4; k++) { A(&tr->fc[k].u, N * tr->fc[k].out); if (k < 3) A(&tr->fc[k].y, N * tr->fc[k].out); }
     A(&tr->loss, 4); A(&tr->state, 4); A(&tr->norm_part, kNormParts);
@@ -1115,10 +1167,28 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         }
         a = L.out;
     }
-    const int spatial = tr->att == LG_ATT_SPATIAL;
+    const int spatial = tr->att == LG_ATT_SPATIAL || tr->att == LG_ATT_HYBRID;
+    const int hid = tr->hid;
     hipLaunchKernelGGL(lgt_att_fwd_kernel, dim3(N), dim3(256), 0, s, a, tr->P_ + tr->att_w, tr->P_ + tr->att_b, spatial, F, P,
                        tr->att_a, tr->gap);
-    const float* fin = tr->gap;
+    const float* pooled = tr->gap;
+    if (hid) {
+        const float* m = tr->gap;   // 'channel': the plain mean is the pooled feature itself
+        if (spatial) {              // 'hybrid': the channel branch pools the unattended map
+            hipLaunchKernelGGL(lgt_att_fwd_kernel, dim3(N), dim3(256), 0, s, a, tr->P_ + tr->att_w, tr->P_ + tr->att_b, 0, F, P,
+                               tr->ca_a1, tr->ca_m);
+            m = tr->ca_m;
+        }
+        const size_t nh = (size_t)N * hid, nf = (size_t)N * F;
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(hid, 4), cdiv(N, 16)), dim3(256), 0, s, m, tr->P_ + tr->ca_w1,
+                           tr->P_ + tr->ca_b1, tr->ca_z1, N, F, hid);
+        hipLaunchKernelGGL(lgt_relu_kernel, dim3(cdiv(nh, 256)), dim3(256), 0, s, tr->ca_z1, tr->ca_r, nh);
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(F, 4), cdiv(N, 16)), dim3(256), 0, s, tr->ca_r, tr->P_ + tr->ca_w2,
+                           tr->P_ + tr->ca_b2, tr->ca_z2, N, hid, F);
+        hipLaunchKernelGGL(lgt_catt_gate_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, s, tr->ca_z2, tr->gap, tr->ca_ca, tr->gap2, nf);
+        pooled = tr->gap2;
+    }
+    const float* fin = pooled;
     for (int k = 0; k < 4; k++) {
         TrainFc& f = tr->fc[k];
         hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(f.out, 4), cdiv(N, 16)), dim3(256), 0, s, fin, tr->P_ + f.w,
@@ -1136,7 +1206,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     const float* dy = tr->dz;
     for (int k = 3; k >= 0; k--) {
         TrainFc& f = tr->fc[k];
-        const float* xin_k = k == 0 ? tr->gap : tr->fc[k - 1].y;
+        const float* xin_k = k == 0 ? pooled : tr->fc[k - 1].y;
         hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(f.in, 64), f.out), dim3(64, kRG), 0, s, dy, xin_k, tr->G + f.w,
                            tr->G + f.b, N, f.in, f.out);
         float* dxk = tr->dfc[0];   // never the buffer dy lives in (dz or dfc[1]): the kernel reads all of dy per output
@@ -1154,8 +1224,26 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     }
     // attention + average pool
     const TrainLayer& last = tr->layers.back();
+    const float* dm = nullptr;
+    if (hid) {   // dy = gradient at g2 = ca * gs
+        const float* m = spatial ? tr->ca_m : tr->gap;
+        const size_t nh = (size_t)N * hid, nf = (size_t)N * F;
+        hipLaunchKernelGGL(lgt_catt_gate_bwd_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, s, dy, tr->ca_ca, tr->gap, tr->ca_dgs,
+                           tr->ca_dz2, nf);
+        hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(hid, 64), F), dim3(64, kRG), 0, s, tr->ca_dz2, tr->ca_r,
+                           tr->G + tr->ca_w2, tr->G + tr->ca_b2, N, hid, F);
+        hipLaunchKernelGGL(lgt_fc_bwd_x_kernel, dim3(cdiv(hid, 64), N), dim3(64, kRG), 0, s, tr->ca_dz2, tr->P_ + tr->ca_w2,
+                           tr->ca_dr, N, hid, F);
+        hipLaunchKernelGGL(lgt_relu_bwd_kernel, dim3(cdiv(nh, 256)), dim3(256), 0, s, tr->ca_dr, tr->ca_z1, tr->ca_dz1, nh);
+        hipLaunchKernelGGL(lgt_fc_bwd_w_kernel, dim3(cdiv(F, 64), hid), dim3(64, kRG), 0, s, tr->ca_dz1, m, tr->G + tr->ca_w1,
+                           tr->G + tr->ca_b1, N, F, hid);
+        hipLaunchKernelGGL(lgt_fc_bwd_x_kernel, dim3(cdiv(F, 64), N), dim3(64, kRG), 0, s, tr->ca_dz1, tr->P_ + tr->ca_w1,
+                           tr->ca_dm, N, F, hid);
+        dy = tr->ca_dgs;
+        dm = tr->ca_dm;
+    }
     hipLaunchKernelGGL(lgt_att_bwd_kernel, dim3(N), dim3(256), 0, s, last.out, tr->att_a, dy, tr->P_ + tr->att_w, spatial, F, P,
-                       tr->dA[0], tr->att_part);
+                       tr->dA[0], tr->att_part, dm);
     if (spatial)
         hipLaunchKernelGGL(lgt_colsum_kernel, dim3(cdiv(F + 1, 64)), dim3(64, kRG), 0, s, tr->att_part, N, F + 1, tr->G + tr->att_w);
     // encoder.  Main chain per layer: BN backward (reduce, dx) -> backward-data convolution; the backward-weights

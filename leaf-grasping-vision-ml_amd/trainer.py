@@ -4,8 +4,8 @@ Mirror of scripts/train_model.py: `normalize_data` (:41-62), the inner optimisat
 forward, BCEWithLogitsLoss(pos_weight=2.0), backward, clip_grad_norm_(1.0), Adam(lr=5e-4, weight_decay=0.01)), the epoch
 loop with WeightedRandomSampler / ReduceLROnPlateau / EarlyStopping (:155-356) and `analyze_predictions` (:64-99).  The
 step itself (forward, backward, optimizer) is lg_train_step of liblgrasp.so -- hand-written gfx950 kernels, no autograd,
-no CPU fallback.  The model is scripts/utils/ml_grasp_optimizer/model.py::GraspPointCNN with attention 'spatial' (the
-training script's model) or 'none'; state dicts use the reference module's key names, so a checkpoint written here is
+no CPU fallback.  The model is scripts/utils/ml_grasp_optimizer/model.py::GraspPointCNN with any of its attention types
+('spatial' = the training script's model) and encoder_filters; state dicts use the reference module's key names, so a checkpoint written here is
 read by GraspPointSelector.load_ml_model (key 'model_state_dict') and by the reference itself.
 
 Dropout: the reference draws its masks from torch's global generator; a different generator cannot reproduce that
@@ -20,7 +20,7 @@ from ._lib import LgError, LgTrainHparams, lib
 
 _VP = C.c_void_p
 _FP = C.POINTER(C.c_float)
-_ATT = {"spatial": 0, "none": 3}
+_ATT = {"spatial": 0, "channel": 1, "hybrid": 2, "none": 3}   # include/leafgrasp.h LG_ATT_*
 
 
 def normalize_data(depth_patches, score_patches):
@@ -63,6 +63,13 @@ def parameter_layout(filters, attention_type="spatial", in_channels=9):
     F = filters[-1]
     if attention_type == "spatial":
         params += [("attention.0.weight", (1, F, 1, 1)), ("attention.0.bias", (1,))]
+    elif attention_type == "channel":           # model.py:37-44
+        params += [("attention.1.weight", (F // 16, F, 1, 1)), ("attention.1.bias", (F // 16,)),
+                   ("attention.3.weight", (F, F // 16, 1, 1)), ("attention.3.bias", (F,))]
+    elif attention_type == "hybrid":            # model.py:45-58
+        params += [("spatial_attention.0.weight", (1, F, 1, 1)), ("spatial_attention.0.bias", (1,)),
+                   ("channel_attention.1.weight", (F // 16, F, 1, 1)), ("channel_attention.1.bias", (F // 16,)),
+                   ("channel_attention.3.weight", (F, F // 16, 1, 1)), ("channel_attention.3.bias", (F,))]
     for idx, i, o in ((0, F, F), (4, F, F // 2), (8, F // 2, F // 4), (12, F // 4, 1)):
         params += [(f"classifier.{idx}.weight", (o, i)), (f"classifier.{idx}.bias", (o,))]
         if idx != 12:
@@ -87,7 +94,7 @@ class GraspTrainer:
         if self.device.type != "cuda":
             raise RuntimeError("GraspTrainer needs a HIP device ('cuda'): no CPU fallback")
         if attention_type not in _ATT:
-            raise ValueError(f"training supports attention_type 'spatial' or 'none', not {attention_type!r}")
+            raise ValueError(f"attention_type must be one of {sorted(_ATT)}, not {attention_type!r}")
         self.attention_type, self.filters = attention_type, tuple(int(f) for f in encoder_filters)
         self.hp = LgTrainHparams(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, pos_weight)
         self.seed, self.max_batch = int(seed), int(max_batch)

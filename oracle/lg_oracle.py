@@ -540,7 +540,7 @@ def cnn_train_step(params, x, y, masks=None, opt_state=None, lr=0.0005, betas=(0
     GraspPointCNN.forward in TRAIN mode (model.py:101-128: batch-statistics BatchNorm with momentum 0.1, Dropout2d(0.3)
     after every encoder block, Dropout(0.5/0.5/0.4) in the classifier), BCEWithLogitsLoss(pos_weight) (:221,251),
     clip_grad_norm_(max_norm) (:256), Adam(lr, weight_decay as L2) (:222,258).
-    params: module state dict (numpy / torch; spatial attention or none).  masks: list of [N, width] keep masks already
+    params: module state dict (numpy / torch; any attention type, recognised from the keys).  masks: list of [N, width] keep masks already
     scaled by 1/(1-p), one per dropout layer in module order (None = no dropout: every mask 1).
     opt_state: {'exp_avg': {k: arr}, 'exp_avg_sq': {...}, 'step': int} or None (fresh optimizer).
     Returns dict(loss, logits, grad_norm, grads, params (updated state dict incl. running statistics), opt_state)."""
@@ -577,8 +577,18 @@ def cnn_train_step(params, x, y, masks=None, opt_state=None, lr=0.0005, betas=(0
         mk = mask(h.shape[1])                       # Dropout2d: one Bernoulli draw per (sample, channel)
         if mk is not None:
             h = h * mk[:, :, None, None]
-    if "attention.0.weight" in p:
+    def chan(prefix):   # AdaptiveAvgPool2d(1) -> 1x1 conv -> ReLU -> 1x1 conv -> Sigmoid   (model.py:37-44)
+        g = h.mean(dim=(2, 3), keepdim=True)
+        z = F.relu(F.conv2d(g, p[f"{prefix}.1.weight"], p[f"{prefix}.1.bias"]))
+        return torch.sigmoid(F.conv2d(z, p[f"{prefix}.3.weight"], p[f"{prefix}.3.bias"]))
+
+    if "attention.0.weight" in p:            # 'spatial'
         h = h * torch.sigmoid(F.conv2d(h, p["attention.0.weight"], p["attention.0.bias"]))
+    elif "attention.1.weight" in p:          # 'channel'
+        h = h * chan("attention")
+    elif "spatial_attention.0.weight" in p:  # 'hybrid': x * spatial(x) * channel(x)   (model.py:115-119)
+        sp = torch.sigmoid(F.conv2d(h, p["spatial_attention.0.weight"], p["spatial_attention.0.bias"]))
+        h = h * sp * chan("channel_attention")
     h = h.mean(dim=(2, 3))
     for idx in (0, 4, 8):
         h = F.linear(h, p[f"classifier.{idx}.weight"], p[f"classifier.{idx}.bias"])

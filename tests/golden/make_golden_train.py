@@ -24,7 +24,7 @@ import synthetic_inputs as S  # noqa: E402
 model = _load_by_path("ref_model", "/root/reference/scripts/utils/ml_grasp_optimizer/model.py")
 torch.set_num_threads(4)
 out = {}
-CASES = (("spatial", (64, 128, 256), 8), ("none", (32, 64, 128), 6))
+CASES = (("spatial", (64, 128, 256), 8), ("none", (32, 64, 128), 6), ("hybrid", (64, 128, 256), 6), ("channel", (32, 64, 128), 8))
 for att, filt, n in CASES:
     tag = f"{att}_{len(filt)}x{filt[0]}"
     params = S.cnn_closed_form_params(seed=3, attention_type=att, filters=filt)

@@ -10,7 +10,7 @@ import synthetic_inputs as S
 from oracle import lg_oracle as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = (("spatial", (64, 128, 256), 8), ("none", (32, 64, 128), 6))
+CASES = (("spatial", (64, 128, 256), 8), ("none", (32, 64, 128), 6), ("hybrid", (64, 128, 256), 6), ("channel", (32, 64, 128), 8))
 
 
 def assert_close_robust(a, b, rtol, atol, max_bad=0.03, l2=0.05, what=""):
@@ -23,6 +23,11 @@ def assert_close_robust(a, b, rtol, atol, max_bad=0.03, l2=0.05, what=""):
     assert bad.mean() <= max_bad, (what, float(bad.mean()), float(np.abs(a - b).max()))
     den = np.linalg.norm(b)
     assert np.linalg.norm(a - b) <= l2 * den + atol * np.sqrt(a.size), (what, float(np.linalg.norm(a - b)), float(den))
+
+
+def noisy_bias(k):
+    """Biases in front of a BatchNorm (encoder convs .0 / .3, classifier Linears .0 / .4 / .8): mathematically zero gradient."""
+    return k.endswith(".bias") and "attention" not in k and k.split(".")[-2] in ("0", "3", "4", "8")
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +72,7 @@ def test_oracle_train_step_matches_reference_fixture(tv, att, filt, n):
     assert_close_robust(vs, tv[f"{tag}_vsample"], 1e-2, 1e-10, what="exp_avg_sq")
     # parameters whose gradient is rounding noise (biases in front of a BatchNorm) take Adam steps of noise sign:
     # up to 2 * lr per step apart; everything else agrees tightly
-    noisy = np.array([k.endswith(".bias") and (k.split(".")[-2] in ("0", "3", "4", "8")) and "attention" not in k for k in names])
+    noisy = np.array([noisy_bias(k) for k in names])
     assert_close_robust(ps[~noisy], tv[f"{tag}_psample"][~noisy], 1e-4, 2e-5, 0.01, 1e-3, what="params")
     np.testing.assert_allclose(ps[noisy], tv[f"{tag}_psample"][noisy], atol=2 * 2 * 0.0005 + 1e-6)
 

@@ -10,7 +10,8 @@ import synthetic_inputs as S  # noqa: E402
 from oracle import lg_oracle as O  # noqa: E402
 from leafgrasp_amd.trainer import GraspTrainer, dropout_layout  # noqa: E402
 
-for att, filt, n, seed in [("none", (64, 128, 256, 512), 8, 2), ("spatial", (128, 256, 512), 5, 3), ("spatial", (32, 64, 128), 16, 4)]:
+for att, filt, n, seed in [("channel", (32, 64, 128), 8, 3), ("hybrid", (64, 128, 256), 6, 7), ("channel", (64, 128, 256), 16, 6),
+                           ("none", (64, 128, 256, 512), 8, 2)]:
     params = S.cnn_closed_form_params(seed=seed, attention_type=att, filters=filt)
     x = S.synthetic_patches(n, seed=20 + seed)
     y = (np.random.default_rng(seed).random(n) < 0.4).astype(np.float32)
