@@ -251,6 +251,12 @@ int lg_train_get_state(lg_trainer* t, float* params, float* buffers, float* exp_
 int lg_train_step(lg_trainer* t, const float* x, const float* labels, int N, const float* masks, uint64_t seed,
                   const lg_train_hparams* hp, int apply_update, float* loss_host, float* grad_norm_host, float* logits_dev);
 int lg_train_sync(lg_trainer* t);
+/* Data-parallel training (one process per GPU): lg_train_step(apply_update = 0) on the rank's shard of the batch, average
+   the flat gradient vector over the ranks (RCCL all-reduce on a tensor wrapping *dev_ptr; lg_train_sync first), then
+   lg_train_apply = clip_grad_norm_ + Adam.step() on the averaged gradients (train_model.py:256-258).  BatchNorm statistics
+   stay per rank, as with torch's DistributedDataParallel without SyncBatchNorm. */
+int lg_train_grad_buffer(lg_trainer* t, float** dev_ptr, int64_t* n);
+int lg_train_apply(lg_trainer* t, const lg_train_hparams* hp, float* grad_norm_host);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,8 @@ SYMBOLS = {
     "lg_train_get_state": (C.c_int, [_VP, _FP, _FP, _FP, _FP, _FP, C.POINTER(C.c_int64)]),
     "lg_train_step": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, C.c_uint64, C.POINTER(LgTrainHparams), C.c_int, _FP, _FP, _VP]),
     "lg_train_sync": (C.c_int, [_VP]),
+    "lg_train_grad_buffer": (C.c_int, [_VP, C.POINTER(_FP), C.POINTER(C.c_int64)]),
+    "lg_train_apply": (C.c_int, [_VP, C.POINTER(LgTrainHparams), _FP]),
 }
 
 

@@ -183,18 +183,33 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[0][0][r] += s_buf[k * 1024 + r * 64 + lane];
     }
+    // epilogue: the 16 bias values of a channel block are fetched together (a load + wait per store would cost as much
+    // as the K loop of a 64-channel layer); CO is a multiple of 32, so a channel block is inside or outside as a whole
+    size_t pix[PB];
+    bool okp[PB];
 #pragma unroll
     for (int i = 0; i < PB; i++) {
         const int q = (wpx * PB + i) * 32 + lm;
         const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
-        if (n >= N) continue;
+        okp[i] = n < N;
+        pix[i] = (size_t)n * CO * WI * WI + (size_t)y * WI + x;
+    }
 #pragma unroll
-        for (int j = 0; j < CB; j++)
+    for (int j = 0; j < CB; j++) {
+        const int cob = co0 + (wco * CB + j) * 32;
+        if (cob >= CO) continue;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) bv[r] = bias ? bias[cob + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < PB; i++) {
+            if (!okp[i]) continue;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int co = co0 + (wco * CB + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (co < CO) out[(((size_t)n * CO + co) * WI + y) * WI + x] = acc[i][j][r] + (bias ? bias[co] : 0.0f);
+                const int co = cob + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[pix[i] + (size_t)co * WI * WI] = acc[i][j][r] + bv[r];
             }
+        }
     }
 }
 
@@ -1356,6 +1371,37 @@ int lg_train_step(lg_trainer* tr, const float* x, const float* labels, int N, co
         TR_HIP(hipStreamSynchronize(s));
         if (loss_host) *loss_host = l;
         if (grad_norm_host) *grad_norm_host = st[1];
+    }
+    return LG_OK;
+}
+
+// Data-parallel training: lg_train_step(apply_update = 0) leaves the rank's gradients in the flat vector below; the
+// caller averages it over the ranks (RCCL all-reduce on the tensor wrapping this pointer) and calls lg_train_apply.
+int lg_train_grad_buffer(lg_trainer* tr, float** dev_ptr, int64_t* n) {
+    if (!tr || !dev_ptr) return LG_ERR_INVALID;
+    *dev_ptr = tr->G;
+    if (n) *n = (int64_t)tr->n_params;
+    return LG_OK;
+}
+
+// clip_grad_norm_ + Adam on the gradient vector as it stands (train_model.py:256-258)
+int lg_train_apply(lg_trainer* tr, const lg_train_hparams* hp, float* grad_norm_host) {
+    if (!tr || !hp) return LG_ERR_INVALID;
+    hipSetDevice(tr->device);
+    hipStream_t s = tr->stream;
+    const AdamHp h = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->max_grad_norm, hp->pos_weight, 0.0f};
+    TR_HIP(hipMemcpyAsync(tr->hp, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
+    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(1), 0, s, tr->norm_part, kNormParts, 1, tr->state);
+    hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
+                       tr->n_params, tr->hp, tr->state);
+    TR_HIP(hipGetLastError());
+    tr->steps++;
+    if (grad_norm_host) {
+        float st[4] = {0.f, 0.f, 0.f, 0.f};
+        TR_HIP(hipMemcpyAsync(st, tr->state, 16, hipMemcpyDeviceToHost, s));
+        TR_HIP(hipStreamSynchronize(s));
+        *grad_norm_host = st[1];
     }
     return LG_OK;
 }

@@ -256,6 +256,30 @@ class GraspTrainer:
             return loss.value, logits, gnorm.value
         return loss.value
 
+    # ------------------------------------------------------------------ data parallel (one process per GPU)
+    def gradient_tensor(self):
+        """The library's flat gradient vector as a torch tensor (no copy): what the ranks all-reduce."""
+        ptr, n = _FP(), C.c_int64()
+        self._check(lib.lg_train_grad_buffer(self._h, C.byref(ptr), C.byref(n)), "lg_train_grad_buffer")
+
+        class _Dev:   # __cuda_array_interface__ v2: torch wraps the device memory without owning it
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f4", "version": 2,
+                                        "data": (C.cast(ptr, C.c_void_p).value, False)}
+        return torch.as_tensor(_Dev(), device=self.device)
+
+    def train_step_ddp(self, batch_x, batch_y, dist, masks=None):
+        """Data-parallel step: every rank runs forward + backward on ITS shard of the batch, the flat gradient vector is
+        averaged over the ranks with one all-reduce (RCCL when the process group's backend is 'nccl'), then every rank
+        applies the same clip + Adam update -- the semantics of torch's DistributedDataParallel around the loop body of
+        train_model.py:247-265 (mean of the per-rank mean losses; BatchNorm statistics per rank).  Returns the rank's loss."""
+        loss = self.train_step(batch_x, batch_y, masks=masks, apply_update=False)   # synchronous: gradients are complete
+        g = self.gradient_tensor()
+        dist.all_reduce(g)
+        g /= dist.get_world_size()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(lib.lg_train_apply(self._h, C.byref(self.hp), None), "lg_train_apply")
+        return loss
+
     # ------------------------------------------------------------------ evaluation (model.eval(): running statistics)
     def predict_logits(self, features, selector=None, batch=4096):
         """Eval-mode logits through the inference path (lg_cnn_forward with the current weights)."""

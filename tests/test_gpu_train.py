@@ -221,3 +221,75 @@ def test_rejects_bad_arguments():
         tr.train_step(np.zeros((9, 9, 32, 32), np.float32), np.zeros(9, np.float32))     # > max_batch
     with pytest.raises(ValueError):
         tr.train_step(np.zeros((4, 9, 32, 32), np.float32), np.zeros(4, np.float32), masks=[np.ones((4, 64), np.float32)])
+
+
+_DDP_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(repo)r)
+import numpy as np, torch, torch.distributed as dist
+import synthetic_inputs as S
+from leafgrasp_amd.trainer import GraspTrainer, dropout_layout
+dist.init_process_group("gloo")            # two ranks on ONE device here; on a node: backend 'nccl' (= RCCL), one GPU per rank
+rank, world = dist.get_rank(), dist.get_world_size()
+filt = (64, 128, 256)
+params = S.cnn_closed_form_params(seed=8, attention_type="spatial", filters=filt)
+x = S.synthetic_patches(16, seed=50)
+y = (np.arange(16) %% 3 == 0).astype(np.float32)
+sl = slice(rank * 8, rank * 8 + 8)
+rng = np.random.default_rng(70 + rank)
+masks = [((rng.random((8, w)) >= p) / (1.0 - p)).astype(np.float32) for w, p in dropout_layout(filt)]
+tr = GraspTrainer(torch.device("cuda:0"), encoder_filters=filt, max_batch=8)
+tr.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+loss = tr.train_step_ddp(x[sl], y[sl], dist, masks=masks)
+out = tr._get(params=True, grads=True, m=True, v=True)
+np.savez(os.path.join(%(out)r, f"rank{rank}.npz"), loss=loss, step=out["step"], **{k: v for k, v in out.items() if k != "step"})
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_step_two_ranks(tmp_path):
+    """Two processes (gloo, both on this one GPU -- the multi-GPU launch uses 'nccl' = RCCL with a GPU per rank): each runs
+    forward + backward on its half of a 16-sample batch, the flat gradient vectors are averaged with one all-reduce, both
+    apply clip + Adam.  The ranks end with identical parameters; the averaged gradient and the update equal the oracle's
+    (two restated half-batch steps averaged, then the restated clip + Adam)."""
+    import socket
+    import subprocess
+    import sys
+    from leafgrasp_amd.trainer import dropout_layout, parameter_layout
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER % {"repo": os.path.dirname(HERE), "out": str(tmp_path)})
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300,
+                         env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["step"]) == 1 and int(r1["step"]) == 1
+    for k in ("params", "grads", "exp_avg", "exp_avg_sq"):      # same averaged gradient -> same update, bit for bit
+        np.testing.assert_array_equal(r0[k], r1[k])
+    filt = (64, 128, 256)
+    params = S.cnn_closed_form_params(seed=8, attention_type="spatial", filters=filt)
+    x = S.synthetic_patches(16, seed=50)
+    y = (np.arange(16) % 3 == 0).astype(np.float32)
+    refs = []
+    for rank in range(2):
+        rng = np.random.default_rng(70 + rank)
+        masks = [((rng.random((8, w)) >= p) / (1.0 - p)).astype(np.float32) for w, p in dropout_layout(filt)]
+        refs.append(O.cnn_train_step(params, x[rank * 8:rank * 8 + 8], y[rank * 8:rank * 8 + 8], masks=masks, apply_update=False))
+    assert float(r0["loss"]) == pytest.approx(refs[0]["loss"], rel=2e-5) and float(r1["loss"]) == pytest.approx(refs[1]["loss"], rel=2e-5)
+    names = [k for k, _ in parameter_layout(filt, "spatial")[0]]
+    gavg = np.concatenate([(0.5 * (refs[0]["grads"][k] + refs[1]["grads"][k])).reshape(-1) for k in names])
+    assert np.linalg.norm(r0["grads"] - gavg) <= 2e-2 * np.linalg.norm(gavg)
+    # restated clip + first Adam step on the averaged gradient (train_model.py:256-258)
+    p0 = np.concatenate([params[k].reshape(-1) for k in names]).astype(np.float64)
+    g = r0["grads"].astype(np.float64)          # the update is checked on the gradient the ranks actually shared
+    coef = min(1.0 / (np.linalg.norm(g) + 1e-6), 1.0)
+    g = g * coef + 0.01 * p0
+    m, v = 0.1 * g, 0.001 * g * g
+    expect = p0 - (0.0005 / 0.1) * (m / (np.sqrt(v) / np.sqrt(0.001) + 1e-8))
+    np.testing.assert_allclose(r0["exp_avg"], m, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(r0["params"], expect, rtol=1e-5, atol=2e-6)
