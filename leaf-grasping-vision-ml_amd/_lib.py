@@ -102,6 +102,11 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    # PyTorch-ROCm ships its own libamdhip64 and every device pointer this package passes comes from torch: torch must be
+    # the one that brings the HIP runtime into the process.  Loaded the other way round, liblgrasp.so binds the system
+    # runtime in /opt/rocm, torch then loads its bundled copy, and the second runtime finds no device
+    # ("lg_create: hipGetDeviceCount -> no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -119,7 +124,7 @@ class LgError(RuntimeError):
 
 def check(handle, rc, what):
     if rc != LG_OK:
-        msg = lib.lg_last_error(handle).decode() if handle else ""
+        msg = lib.lg_last_error(handle if handle else None).decode()   # NULL handle: the reason lg_create failed
         raise LgError(f"{what} failed with status {rc}: {msg}")
 
 

@@ -297,11 +297,20 @@ void lg_default_params(lg_params* p) {
     p->mask_is_bool = 1;
 }
 
+static thread_local std::string g_create_err = "null handle";
+
 int lg_create(int device, lg_handle* out) {
     if (!out) return LG_ERR_INVALID;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return LG_ERR_HIP;
+    {
+        const hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || device < 0 || device >= n) {
+            g_create_err = std::string("lg_create: hipGetDeviceCount -> ") + hipGetErrorString(e) + ", " + std::to_string(n) +
+                           " device(s), asked for " + std::to_string(device);
+            return LG_ERR_HIP;
+        }
+    }
     lg_ctx* h = new (std::nothrow) lg_ctx();
     if (!h) return LG_ERR_NOMEM;
     h->device = device;
@@ -315,6 +324,7 @@ int lg_create(int device, lg_handle* out) {
         hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
     }
@@ -323,6 +333,7 @@ int lg_create(int device, lg_handle* out) {
         hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->s_topk, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming) != hipSuccess) {
+        g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
     }
@@ -356,7 +367,7 @@ int lg_destroy(lg_handle h) {
     return LG_OK;
 }
 
-const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : "null handle"; }
+const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }   // NULL: why lg_create failed
 
 int lg_profile_enable(lg_handle h, int on) {
     if (!h) return LG_ERR_INVALID;
