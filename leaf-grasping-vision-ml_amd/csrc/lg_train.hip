@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict
     for (int k = 0; k < 16; k++) w[k] = lane + 64 * k < I ? W[(size_t)o * I + lane + 64 * k] : 0.0f;
     const float bo = b[o];
     const int nk = (I + 63) / 64;
+#pragma unroll 4   // independent samples: their loads and shuffle chains overlap
     for (int n = blockIdx.y * 16; n < min(N, (int)blockIdx.y * 16 + 16); n++) {
         float s = 0.0f;
 #pragma unroll
@@ -776,9 +777,12 @@ __global__ __launch_bounds__(256) void lgt_sumsq_kernel(const float* __restrict_
 
 // state[0] = step count (float), state[1] = total gradient norm of this step (before clipping).  One wave adds the
 // partial sums in index order and advances the step count when the optimizer runs.
-__global__ void lgt_norm_kernel(const float* __restrict__ partial, int nparts, int advance, float* __restrict__ state) {
-    float ss = 0.0f;
-    for (int k = 0; k < nparts; k++) ss += partial[k];
+__global__ __launch_bounds__(64) void lgt_norm_kernel(const float* __restrict__ partial, int nparts, int advance,
+                                                      float* __restrict__ state) {
+    float ss = 0.0f;   // one wave: lane l adds partials l, l + 64, ... in order, then a fixed butterfly
+    for (int k = threadIdx.x; k < nparts; k += 64) ss += partial[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (threadIdx.x == 0) {
         state[1] = sqrtf(ss);
         if (advance) state[0] += 1.0f;
@@ -878,8 +882,13 @@ int wgrad_split(int ntiles, size_t nw, int blocks) {
     const size_t want = std::max<size_t>(8, (size_t)(1024 / std::max(1, blocks)));
     return (int)std::min<size_t>(std::min<size_t>((size_t)ntiles, std::min<size_t>(want, (size_t)kMaxSplit)), cap);
 }
-// sample chunks of the BatchNorm reductions: enough workgroups to fill the chip, never more chunks than samples
-int bn_chunks(int N, int C) { return N < 64 ? 1 : std::max(1, std::min(std::min(N / 4, kBnSplit), 2048 / C)); }
+// sample chunks of the BatchNorm reductions: about 4096 elements per workgroup, at most 2048 workgroups, never more
+// chunks than samples (batch 16 at 32x32: 4 chunks instead of one workgroup walking 16384 elements three times)
+int bn_chunks(int N, int C, int HW) {
+    const long long M = (long long)N * HW;
+    const int want = (int)std::min<long long>(M / 4096, (long long)kBnSplit);
+    return std::max(1, std::min(std::min(want, N), std::max(1, 2048 / C)));
+}
 
 #define TR_HIP(call)                                                                                     \
     do {                                                                                                 \
@@ -1165,7 +1174,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     const float* a = tr->xin;
     for (auto& L : tr->layers) {
         launch_conv(L.wi, s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
-        const int S = bn_chunks(N, L.co), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
+        const int S = bn_chunks(N, L.co, L.wi * L.wi), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         hipLaunchKernelGGL(lgt_bn_stats_kernel, dim3(L.co, Sy), dim3(256), 0, s, L.x, N, L.co, L.wi * L.wi, chunk, eps, mom,
                            tr->bn_part, tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
         if (Sy > 1)
@@ -1274,7 +1283,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         const float *mu = tr->mean + L.st, *rs = tr->rstd + L.st, *g = tr->P_ + L.g, *be = tr->P_ + L.be;
         float* dXl = tr->dX[li & 1];
         if (li + 2 < nl) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li + 2], 0));
-        const int S = bn_chunks(N, L.co), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
+        const int S = bn_chunks(N, L.co, L.wi * L.wi), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         if (L.pool) {
             hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
                                tr->G + L.g, tr->G + L.be, tr->bn_part, chunk, dXl, N, L.co, L.wi);
@@ -1310,7 +1319,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     for (int li = 0; li < std::min(2, nl); li++) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li], 0));   // sw is in order: 0 covers all
     // ---------------- optimizer
     hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
-    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(1), 0, s, tr->norm_part, kNormParts, apply_update ? 1 : 0, tr->state);
+    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(64), 0, s, tr->norm_part, kNormParts, apply_update ? 1 : 0, tr->state);
     if (apply_update)
         hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
                            tr->n_params, tr->hp, tr->state);
@@ -1392,7 +1401,7 @@ int lg_train_apply(lg_trainer* tr, const lg_train_hparams* hp, float* grad_norm_
     const AdamHp h = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->max_grad_norm, hp->pos_weight, 0.0f};
     TR_HIP(hipMemcpyAsync(tr->hp, &h, sizeof(h), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
-    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(1), 0, s, tr->norm_part, kNormParts, 1, tr->state);
+    hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(64), 0, s, tr->norm_part, kNormParts, 1, tr->state);
     hipLaunchKernelGGL(lgt_adam_kernel, dim3(cdiv(tr->n_params, 256)), dim3(256), 0, s, tr->P_, tr->G, tr->M, tr->V,
                        tr->n_params, tr->hp, tr->state);
     TR_HIP(hipGetLastError());
