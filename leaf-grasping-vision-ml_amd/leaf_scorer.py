@@ -143,6 +143,11 @@ class OptimalLeafSelector:
         except Exception as e:  # noqa: BLE001
             logerr(f"Error in leaf selection: {str(e)}")
             return [None] * len(mask_tensors)
+        return self.select_from_statistics_batch(per_frame)
+
+    def select_from_statistics_batch(self, per_frame):
+        """The host half of select_optimal_leaves_batch: per-frame candidate scores, Pareto set and weighted pick from the
+        statistics of leaf_statistics_batch (kept separate so that a caller can run it beside the next chunk's device pass)."""
         out, tall = [], []
         for fr in per_frame:
             if fr is None:

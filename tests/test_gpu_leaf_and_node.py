@@ -187,3 +187,7 @@ def test_leaf_selection_batch_equals_per_frame(L):
     csv_b = hz.process_batch(labels.astype(np.uint16).reshape(len(frames), -1), depths.reshape(len(frames), -1))
     csv_s = [hz.process(labels[b].astype(np.uint16).reshape(-1), depths[b].reshape(-1)) for b in range(len(frames))]
     assert csv_b == csv_s and csv_b[5] is None
+    # the chunked path (leaf statistics of chunk k+1 in a worker thread beside selection + grasp pass of chunk k)
+    for chunks in (1, 2, 3, len(frames)):
+        assert hz.process_batch_device(lab_d, dep_d, chunks=chunks) == csv_s, chunks
+        assert hz.last_leaf_ids == ids
