@@ -42,7 +42,7 @@ struct Tile {
     static constexpr int BANDS = WI / TR;
     static constexpr int TW = WI + 2, TH = TR + 2;          // staged rows / columns (halo 1)
     static constexpr int PLANE = TS * TH * TW;              // staged floats per channel
-    __device__ static int halo(int q) {                     // offset of the 3x3 window's top-left for tile pixel q
+    __device__ static constexpr int halo(int q) {           // offset of the 3x3 window's top-left for tile pixel q
         const int ts = q / (TR * WI), row = (q / WI) % TR, x = q % WI;
         return (ts * TH + row) * TW + x;
     }
@@ -215,63 +215,103 @@ __global__ __launch_bounds__(256) void lgt_conv_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------ conv wgrad
 // partial[s][tap][ci][co] = sum over the pixel tiles of slice s of a[n][ci][y+ky-1][x+kx-1] * dx[n][co][y][x]
-// Workgroup: 64 ci x 64 co (wave: 32 x 32, nine tap accumulators), kWgTile pixels per K tile; LDS and registers sized for
-// two workgroups per CU (one workgroup stages while the other multiplies).
-constexpr int kWgTile = 64;
+// Workgroup: 32 ci x 64 co, six waves = 2 blocks of 32 output channels x 3 kernel rows; a wave owns the three tap
+// accumulators of its row (M = 32 input channels read at the tap's halo offset, N = 32 output channels, K = pixels).
+// The input halo tile and the dX tile of kWgTile pixels stream into a double-buffered LDS image with global_load_lds
+// (slot idx = t + 384 j lands at float idx; the odd row strides that keep the operand reads conflict-free are slots that
+// fetch the zero word); source offsets relative to the tile origin are computed once.  ~100 VGPRs, 62 KB LDS: two
+// workgroups = 12 waves per CU, three per SIMD.
+constexpr int kWgTile = 64, kWgThreads = 384;
 template <int WI>
-__global__ __launch_bounds__(256, 2) void lgt_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dx,
-                                                        float* __restrict__ partial, int N, int CI, int CO, int ntiles) {
+__global__ __launch_bounds__(kWgThreads, 2) void lgt_wgrad_kernel(const float* __restrict__ a, const float* __restrict__ dx,
+                                                                float* __restrict__ partial, int N, int CI, int CO, int ntiles) {
     using T = Tile<WI, kWgTile>;
-    constexpr int SD = kWgTile + 1, SI = T::PLANE | 1;
-    __shared__ float s_d[64 * SD];
-    __shared__ float s_i[64 * SI];
+    constexpr int SD = kWgTile + 1, SI = T::PLANE | 1, NT = kWgThreads;
+    constexpr int NSD = (64 * SD + NT - 1) / NT, NSI = (32 * SI + NT - 1) / NT, BUF = (NSD + NSI) * NT;
+    __shared__ __attribute__((aligned(16))) float s_buf[2 * BUF];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 31, kh = lane >> 5;
-    const int wc = wave & 1, wi = wave >> 1;
-    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
-    const bool active = ci0 + wi * 32 < CI && co0 + wc * 32 < CO;
+    const int wc = wave & 1, ky = wave >> 1;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 32;
+    const bool active = co0 + wc * 32 < CO;
 
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++)
+    for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR;
-        __syncthreads();
-        for (int idx = t; idx < 64 * kWgTile; idx += 256) {
-            const int co = idx / kWgTile, q = idx % kWgTile;
-            const int n = n0 + q / (T::TR * WI), y = y0 + (q / WI) % T::TR, x = q % WI;
-            s_d[co * SD + q] = (n < N && co0 + co < CO) ? dx[(((size_t)n * CO + co0 + co) * WI + y) * WI + x] : 0.0f;
-        }
-        for (int idx = t; idx < 64 * T::PLANE; idx += 256) {
-            const int ci = idx / T::PLANE, r = idx % T::PLANE;
-            const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
-            const int gy = y0 - 1 + ry, gx = rx - 1, n = n0 + ts;
-            const bool ok = n < N && ci0 + ci < CI && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
-            s_i[ci * SI + r] = ok ? a[(((size_t)n * CI + ci0 + ci) * WI + gy) * WI + gx] : 0.0f;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 4
-            for (int q0 = 0; q0 < kWgTile; q0 += 2) {
-                const int q = q0 + kh;
-                const float b = s_d[(wc * 32 + lm) * SD + q];
-                const float* ai = s_i + (wi * 32 + lm) * SI + T::halo(q);
+    // tile-invariant part of the source offsets (relative to sample n0, row y0); kNever: the slot always loads zero
+    constexpr int kNever = -2147483647 - 1;
+    int rel_d[NSD], rel_i[NSI];
+    unsigned meta_i[(NSI + 3) / 4], meta_d[(NSD + 3) / 4];   // per slot: (sample within the tile) << 4 | halo row
 #pragma unroll
-                for (int tap = 0; tap < 9; tap++)
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[(tap / 3) * T::TW + tap % 3], b, acc[tap], 0, 0, 0);
+    for (int j = 0; j < (NSI + 3) / 4; j++) meta_i[j] = 0;
+#pragma unroll
+    for (int j = 0; j < (NSD + 3) / 4; j++) meta_d[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NSD; j++) {
+        const int idx = t + NT * j, co = idx / SD, q = idx % SD;
+        const int ts = q / (T::TR * WI), row = (q / WI) % T::TR, x = q % WI;
+        const bool ok = idx < 64 * SD && q < kWgTile && co0 + co < CO;
+        rel_d[j] = ok ? ((ts * CO + co0 + co) * WI + row) * WI + x : kNever;
+        meta_d[j >> 2] |= (unsigned)(ts << 4) << (8 * (j & 3));
+    }
+#pragma unroll
+    for (int j = 0; j < NSI; j++) {
+        const int idx = t + NT * j, ci = idx / SI, r = idx % SI;
+        const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
+        const bool ok = idx < 32 * SI && r < T::PLANE && ci0 + ci < CI && rx >= 1 && rx <= WI;
+        rel_i[j] = ok ? ((ts * CI + ci0 + ci) * WI + ry - 1) * WI + rx - 1 : kNever;
+        meta_i[j >> 2] |= (unsigned)((ts << 4) | ry) << (8 * (j & 3));
+    }
+    auto issue_tile = [&](int tile, int stage) {
+        float* sb = s_buf + stage * BUF;
+        const int n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR;
+        const float* d0 = dx + ((size_t)n0 * CO * WI + y0) * WI;
+        const float* a0 = a + ((size_t)n0 * CI * WI + y0) * WI;
+#pragma unroll
+        for (int j = 0; j < NSD; j++) {
+            const int ts = (meta_d[j >> 2] >> (8 * (j & 3) + 4)) & 15;
+            const float* src = (rel_d[j] != kNever && n0 + ts < N) ? d0 + rel_d[j] : lgt_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + NT * j + 64 * wave), 4, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NSI; j++) {
+            const unsigned m = (meta_i[j >> 2] >> (8 * (j & 3))) & 255u;
+            const int gy = y0 - 1 + (int)(m & 15u);
+            const float* src = (rel_i[j] != kNever && n0 + (int)(m >> 4) < N && gy >= 0 && gy < WI) ? a0 + rel_i[j] : lgt_zero_pad;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + NT * (NSD + j) + 64 * wave), 4, 0, 0);
+        }
+    };
+    int stage = 0;
+    if ((int)blockIdx.x < ntiles) issue_tile(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, stage ^= 1) {
+        __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
+        if (tile + (int)gridDim.x < ntiles) issue_tile(tile + gridDim.x, stage ^ 1);
+        if (active) {
+            // pixel q0 + kh sits right of the even pixel q0 in the same image row: halo(q0 + kh) = halo(q0) + kh, so the
+            // fully unrolled loop reads at compile-time offsets from two per-lane base pointers (no VALU between MFMAs)
+            const float* bb = s_buf + stage * BUF + (wc * 32 + lm) * SD + kh;
+            const float* ab = s_buf + stage * BUF + NSD * NT + lm * SI + ky * T::TW + kh;
+#pragma unroll
+            for (int q0 = 0; q0 < kWgTile; q0 += 2) {
+                const float b = bb[q0];
+                const float* ai = ab + T::halo(q0);
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kx], b, acc[kx], 0, 0, 0);
             }
         }
     }
     if (!active) return;
     const int co = co0 + wc * 32 + lm;
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++)
+    for (int kx = 0; kx < 3; kx++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (ci < CI && co < CO) partial[(((size_t)blockIdx.x * 9 + tap) * CI + ci) * CO + co] = acc[tap][r];
+            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (ci < CI && co < CO) partial[(((size_t)blockIdx.x * 9 + ky * 3 + kx) * CI + ci) * CO + co] = acc[kx][r];
         }
 }
 
@@ -645,15 +685,20 @@ __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict
     for (int k = 0; k < 16; k++) w[k] = lane + 64 * k < I ? W[(size_t)o * I + lane + 64 * k] : 0.0f;
     const float bo = b[o];
     const int nk = (I + 63) / 64;
-#pragma unroll 4   // independent samples: their loads and shuffle chains overlap
-    for (int n = blockIdx.y * 16; n < min(N, (int)blockIdx.y * 16 + 16); n++) {
-        float s = 0.0f;
+    const int nb = blockIdx.y * 16, ne = min(N, nb + 16);
+    for (int n = nb; n < ne; n += 4) {   // four independent samples at a time: their loads and shuffle chains overlap
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < nk) s += (lane + 64 * k < I ? X[(size_t)n * I + lane + 64 * k] : 0.0f) * w[k];
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
-        if (lane == 0) Y[(size_t)n * O + o] = s + bo;
+            for (int k = 0; k < 16; k++)
+                if (k < nk && n + u < ne) s4[u] += (lane + 64 * k < I ? X[(size_t)(n + u) * I + lane + 64 * k] : 0.0f) * w[k];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int k = 32; k > 0; k >>= 1) s4[u] += __shfl_xor(s4[u], k, 64);
+            if (lane == 0 && n + u < ne) Y[(size_t)(n + u) * O + o] = s4[u] + bo;
+        }
     }
 }
 
@@ -939,10 +984,10 @@ void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const 
 void launch_wgrad(int wi, dim3 grid, hipStream_t s, const float* a, const float* dx, float* partial, int N, int CI, int CO,
                   int ntiles) {
     switch (wi) {
-        case 32: hipLaunchKernelGGL(lgt_wgrad_kernel<32>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
-        case 16: hipLaunchKernelGGL(lgt_wgrad_kernel<16>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
-        case 8: hipLaunchKernelGGL(lgt_wgrad_kernel<8>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
-        default: hipLaunchKernelGGL(lgt_wgrad_kernel<4>, grid, dim3(256), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        case 32: hipLaunchKernelGGL(lgt_wgrad_kernel<32>, grid, dim3(kWgThreads), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        case 16: hipLaunchKernelGGL(lgt_wgrad_kernel<16>, grid, dim3(kWgThreads), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        case 8: hipLaunchKernelGGL(lgt_wgrad_kernel<8>, grid, dim3(kWgThreads), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
+        default: hipLaunchKernelGGL(lgt_wgrad_kernel<4>, grid, dim3(kWgThreads), 0, s, a, dx, partial, N, CI, CO, ntiles); break;
     }
 }
 int conv_tiles(int wi, int N, int tile) {   // pixel tiles of `tile` pixels covering N samples
@@ -1049,7 +1094,7 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
         A(&L.wpf, (size_t)9 * L.ci * L.co);
         A(&L.wpd, (size_t)9 * L.ci * L.co);
         max_act = std::max(max_act, std::max(full, N * L.ci * L.wi * L.wi));
-        const int tiles = wgrad_split(conv_tiles(L.wi, max_batch, kWgTile), (size_t)9 * L.ci * L.co, (int)(cdiv(L.co, 64) * cdiv(L.ci, 64)));
+        const int tiles = wgrad_split(conv_tiles(L.wi, max_batch, kWgTile), (size_t)9 * L.ci * L.co, (int)(cdiv(L.co, 64) * cdiv(L.ci, 32)));
         tr->partial_floats = std::max(tr->partial_floats, (size_t)tiles * 9 * L.ci * L.co);
     }
     A(&tr->dA[0], max_act); A(&tr->dA[1], max_act); A(&tr->dX[0], max_act); A(&tr->dX[1], max_act);
@@ -1307,8 +1352,8 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         TR_HIP(hipEventRecord(tr->ev_dx[li], s));
         TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));
         const size_t nw = (size_t)9 * L.ci * L.co;
-        const int ntiles = conv_tiles(L.wi, N, kWgTile), Sw = wgrad_split(ntiles, nw, (int)(cdiv(L.co, 64) * cdiv(L.ci, 64)));
-        launch_wgrad(L.wi, dim3(Sw, cdiv(L.co, 64), cdiv(L.ci, 64)), sw, ain, dXl, tr->partial, N, L.ci, L.co, ntiles);
+        const int ntiles = conv_tiles(L.wi, N, kWgTile), Sw = wgrad_split(ntiles, nw, (int)(cdiv(L.co, 64) * cdiv(L.ci, 32)));
+        launch_wgrad(L.wi, dim3(Sw, cdiv(L.co, 64), cdiv(L.ci, 32)), sw, ain, dXl, tr->partial, N, L.ci, L.co, ntiles);
         hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, sw, tr->partial, Sw, L.ci, L.co, tr->G + L.w);
         TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
         if (li > 0) {   // backward-data: a convolution of dX with the mirrored, channel-swapped weights
