@@ -33,6 +33,21 @@ def normalize_data(depth_patches, score_patches):
             "stats": {"depth_mean": depth_mean, "depth_std": depth_std, "score_mean": score_mean, "score_std": score_std}}
 
 
+def prepare_features(data, device=None):
+    """train_model.py:167-180 -- the training_data.pt dict (EnhancedGraspDataCollector's layout: 'depth_patches' [n,32,32],
+    'mask_patches' [n,32,32], 'score_patches' [n,7,32,32], 'labels' [n]) -> (features [n,9,32,32], labels [n] float,
+    normalization stats): depth and mask get their channel axis, depth / scores are z-scored by normalize_data, channels
+    are concatenated as [depth, mask, scores]."""
+    to = (lambda t: t.to(device)) if device is not None else (lambda t: t)
+    depth = to(torch.as_tensor(data["depth_patches"]).float()).unsqueeze(1)
+    mask = to(torch.as_tensor(data["mask_patches"]).float()).unsqueeze(1)
+    scores = to(torch.as_tensor(data["score_patches"]).float())
+    labels = to(torch.as_tensor(data["labels"]).float())
+    normalized = normalize_data(depth, scores)
+    features = torch.cat([normalized["depth_patches"], mask, normalized["score_patches"]], dim=1)
+    return features, labels, normalized["stats"]
+
+
 def analyze_predictions(outputs, labels, threshold=0.5):
     """train_model.py:64-99 (same keys; note the reference thresholds the LOGITS at 0.5 here)."""
     predicted = (outputs.squeeze() > threshold).float()
@@ -212,6 +227,31 @@ class GraspTrainer:
         return {"exp_avg": self._unflat(o["exp_avg"], self._params),
                 "exp_avg_sq": self._unflat(o["exp_avg_sq"], self._params), "step": o["step"]}
 
+    def torch_optimizer_state_dict(self):
+        """The optimizer state in torch.optim.Adam.state_dict() layout ('state' by parameter index in model.parameters()
+        order, one param group): what the reference stores as 'optimizer_state_dict' (train_model.py:326) and what
+        torch.optim.Adam(model.parameters(), ...).load_state_dict accepts."""
+        o = self.optimizer_state()
+        state = {i: {"step": torch.tensor(float(o["step"])), "exp_avg": o["exp_avg"][k], "exp_avg_sq": o["exp_avg_sq"][k]}
+                 for i, (k, _) in enumerate(self._params)} if o["step"] > 0 else {}
+        group = {"lr": float(self.hp.lr), "betas": (float(self.hp.beta1), float(self.hp.beta2)), "eps": float(self.hp.eps),
+                 "weight_decay": float(self.hp.weight_decay), "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self._params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_optimizer_state_dict(self, osd, module_state_dict=None):
+        """Inverse of torch_optimizer_state_dict (resume from a checkpoint written by the reference or by fit())."""
+        st = osd["state"]
+        step = int(st[0]["step"]) if st else 0
+        zeros = {k: torch.zeros(shape) for k, shape in self._params}
+        m = {k: (st[i]["exp_avg"] if i in st else zeros[k]) for i, (k, _) in enumerate(self._params)}
+        v = {k: (st[i]["exp_avg_sq"] if i in st else zeros[k]) for i, (k, _) in enumerate(self._params)}
+        g = osd["param_groups"][0]
+        self.hp.lr, (self.hp.beta1, self.hp.beta2) = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1]))
+        self.hp.eps, self.hp.weight_decay = float(g["eps"]), float(g["weight_decay"])
+        self.load_state_dict(module_state_dict if module_state_dict is not None else self.state_dict(),
+                             {"exp_avg": m, "exp_avg_sq": v, "step": step})
+
     @property
     def lr(self):
         return self.hp.lr
@@ -351,7 +391,8 @@ class GraspTrainer:
                 if save_dir:
                     os.makedirs(save_dir, exist_ok=True)
                     torch.save({"epoch": epoch, "model_state_dict": self.state_dict(),
-                                "optimizer_state_dict": self.optimizer_state(), "val_loss": best_val, "metrics": metrics,
+                                "optimizer_state_dict": self.torch_optimizer_state_dict(), "val_loss": best_val,
+                                "metrics": metrics,
                                 "normalization_stats": normalization_stats, "train_losses": train_losses,
                                 "val_losses": val_losses, "metrics_history": metrics_history},
                                os.path.join(save_dir, "best_model.pth"))

@@ -208,6 +208,21 @@ def test_training_reduces_loss_and_feeds_inference_path(tmp_path):
     assert sel.ml_predictor is not None
     ck = torch.load(tmp_path / "best_model.pth", map_location="cpu", weights_only=True)
     assert {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "metrics", "train_losses", "val_losses"} <= set(ck)
+    # the optimizer state is in torch.optim.Adam's own layout: a stock Adam over same-shaped parameters loads it, and the
+    # trainer resumes from it bit for bit
+    from leafgrasp_amd.trainer import parameter_layout
+    plist = [torch.nn.Parameter(torch.zeros(shape)) for _, shape in parameter_layout((64, 128, 256), "spatial")[0]]
+    topt = torch.optim.Adam(plist, lr=0.1)
+    topt.load_state_dict(ck["optimizer_state_dict"])
+    assert topt.param_groups[0]["lr"] == pytest.approx(0.0005) and topt.param_groups[0]["weight_decay"] == pytest.approx(0.01)
+    osd = tr.torch_optimizer_state_dict()
+    assert int(osd["state"][0]["step"]) == tr.optimizer_state()["step"] > 0
+    tr2 = make_trainer("spatial", (64, 128, 256), 16, seed=7)
+    tr2.load_torch_optimizer_state_dict(osd, tr.state_dict())
+    a, b = tr._get(params=True, m=True, v=True), tr2._get(params=True, m=True, v=True)
+    for key in ("params", "exp_avg", "exp_avg_sq"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert a["step"] == b["step"]
 
 
 def test_rejects_bad_arguments():

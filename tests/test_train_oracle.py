@@ -121,3 +121,20 @@ def test_trainer_has_no_cpu_fallback():
     from leafgrasp_amd.trainer import GraspTrainer
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         GraspTrainer(torch.device("cpu"))
+
+
+def test_prepare_features_follows_the_training_script():
+    """train_model.py:167-180: unsqueeze, normalize_data, cat([depth, mask, scores])."""
+    from leafgrasp_amd.trainer import normalize_data, prepare_features
+    rng = np.random.default_rng(1)
+    data = {"depth_patches": torch.from_numpy(rng.random((6, 32, 32)).astype(np.float32)),
+            "mask_patches": torch.from_numpy((rng.random((6, 32, 32)) > 0.5).astype(np.float32)),
+            "score_patches": torch.from_numpy(rng.random((6, 7, 32, 32)).astype(np.float32)),
+            "labels": torch.tensor([1, 0, 1, 0, 0, 1])}
+    f, y, stats = prepare_features(data)
+    assert tuple(f.shape) == (6, 9, 32, 32) and y.dtype == torch.float32
+    n = normalize_data(data["depth_patches"].unsqueeze(1), data["score_patches"])
+    torch.testing.assert_close(f[:, 0:1], n["depth_patches"])
+    torch.testing.assert_close(f[:, 1], data["mask_patches"])
+    torch.testing.assert_close(f[:, 2:], n["score_patches"])
+    assert set(stats) == {"depth_mean", "depth_std", "score_mean", "score_std"}
