@@ -896,7 +896,6 @@ struct lg_trainer {
     float *ca_dgs = nullptr, *ca_dz2 = nullptr, *ca_dr = nullptr, *ca_dz1 = nullptr, *ca_dm = nullptr, *ca_a1 = nullptr;
     size_t n_params = 0, n_buffers = 0, n_stats = 0, mask_row = 0;
     float drop2d_p = 0.3f, drop_p[3] = {0.5f, 0.5f, 0.4f};
-    size_t mask_fc[3] = {0, 0, 0};
     float *P_ = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *B = nullptr, *mean = nullptr, *rstd = nullptr;
     float *xin = nullptr, *labels = nullptr, *masks = nullptr;
     float *dA[2] = {nullptr, nullptr}, *dX[2] = {nullptr, nullptr}, *partial = nullptr, *bn_part = nullptr;
@@ -1121,6 +1120,12 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
             hipEventCreateWithFlags(&tr->ev_wg[k], hipEventDisableTiming) != hipSuccess) rc = LG_ERR_HIP;
     if (rc != LG_OK) {
         for (void* q : tr->allocs) hipFree(q);
+        for (int k = 0; k < 8; k++) {
+            if (tr->ev_dx[k]) hipEventDestroy(tr->ev_dx[k]);
+            if (tr->ev_wg[k]) hipEventDestroy(tr->ev_wg[k]);
+        }
+        if (tr->stream) hipStreamDestroy(tr->stream);
+        if (tr->stream_w) hipStreamDestroy(tr->stream_w);
         delete tr;
         return rc;
     }
