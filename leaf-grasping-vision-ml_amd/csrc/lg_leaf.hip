@@ -81,6 +81,34 @@ struct LeafAcc {  // device accumulators, one per slot
     int pad;
 };
 
+// The LGL_RUN labels of a run in registers: two 16-byte loads when the row pitch and the base allow it (a wave then reads
+// 2 KB of consecutive labels), element loads otherwise.  Returns false for a run without a positive label -- most runs of a
+// frame are background, and they end here after one 32-byte read.
+__device__ inline bool load_run(const int16_t* __restrict__ lab, int W, int y, int x0, int x1, bool vec, int16_t (&ids)[LGL_RUN]) {
+    static_assert(LGL_RUN == 16, "two uint4 loads per run");
+    const int16_t* p = lab + (size_t)y * W + x0;
+    if (vec && x1 - x0 == LGL_RUN) {
+        const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+        if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u) return false;
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ids[2 * k] = (int16_t)(w[k] & 0xFFFFu);
+            ids[2 * k + 1] = (int16_t)(w[k] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LGL_RUN; k++) ids[k] = (x0 + k < x1) ? p[k] : (int16_t)0;
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < LGL_RUN; k++) any |= ids[k] > 0;
+    return any;
+}
+__device__ inline bool run_vec_ok(const int16_t* lab, int W) {
+    return (W % LGL_RUN) == 0 && (reinterpret_cast<uintptr_t>(lab) & 15u) == 0;
+}
+
 // ---------------------------------------------------------------- per-slot sums
 __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ lab, const float* __restrict__ depth,
                                                     int H, int W, const unsigned long long* __restrict__ pres,
@@ -101,14 +129,19 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
     const long long nruns = (long long)H * runs_per_row;
     const double f2 = (double)f * (double)f;
+    const bool vec = run_vec_ok(lab, W);
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
         const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
         const int x1 = min(x0 + LGL_RUN, W);
+        int16_t ids[LGL_RUN];
+        if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
         int cur = 0;
         unsigned long long a = 0; long long sx = 0; double sd = 0.0, sr = 0.0; int bd = 0;
         const double dy = (double)y - (double)cy;
-        for (int x = x0; x <= x1; x++) {
-            int id = (x < x1) ? (int)lab[(size_t)y * W + x] : 0;
+#pragma unroll
+        for (int k = 0; k <= LGL_RUN; k++) {
+            const int x = x0 + k;
+            int id = (k < LGL_RUN) ? (int)ids[k < LGL_RUN ? k : 0] : 0;   // k == LGL_RUN: flush (labels past x1 are 0)
             if (id < 0) id = 0;
             if (id != cur) {
                 if (cur > 0 && a) {
@@ -183,15 +216,20 @@ __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, c
     __syncthreads();
     const int shift = 8 * pass;
     const uint32_t himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const bool vec = run_vec_ok(lab, W);
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
     const long long nruns = (long long)H * runs_per_row;
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
         const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
         const int x1 = min(x0 + LGL_RUN, W);
+        int16_t ids[LGL_RUN];
+        if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
         int cur_id = 0, cur_slot = -1, cur_bin = -1;
         uint32_t cnt = 0, cur_prefix = 0;
-        for (int x = x0; x < x1; x++) {
-            int id = (int)lab[(size_t)y * W + x];
+#pragma unroll
+        for (int k = 0; k < LGL_RUN; k++) {
+            const int x = x0 + k;
+            int id = (int)ids[k];
             if (id <= 0) continue;
             if (id != cur_id) {
                 if (cnt) { atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt); cnt = 0; }
