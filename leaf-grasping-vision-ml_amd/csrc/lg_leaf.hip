@@ -105,8 +105,22 @@ __device__ inline bool load_run(const int16_t* __restrict__ lab, int W, int y, i
     for (int k = 0; k < LGL_RUN; k++) any |= ids[k] > 0;
     return any;
 }
-__device__ inline bool run_vec_ok(const int16_t* lab, int W) {
-    return (W % LGL_RUN) == 0 && (reinterpret_cast<uintptr_t>(lab) & 15u) == 0;
+// the depths of a run that holds leaf pixels: four 16-byte loads (same conditions as load_run's vector path)
+__device__ inline void load_run_depth(const float* __restrict__ depth, int W, int y, int x0, int x1, bool vec, float (&dv)[LGL_RUN]) {
+    const float* p = depth + (size_t)y * W + x0;
+    if (vec && x1 - x0 == LGL_RUN) {
+#pragma unroll
+        for (int k = 0; k < LGL_RUN / 4; k++) {
+            const float4 v = reinterpret_cast<const float4*>(p)[k];
+            dv[4 * k] = v.x; dv[4 * k + 1] = v.y; dv[4 * k + 2] = v.z; dv[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LGL_RUN; k++) dv[k] = (x0 + k < x1) ? p[k] : 0.0f;
+    }
+}
+__device__ inline bool run_vec_ok(const int16_t* lab, const float* depth, int W) {
+    return (W % LGL_RUN) == 0 && (reinterpret_cast<uintptr_t>(lab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0;
 }
 
 // ---------------------------------------------------------------- per-slot sums
@@ -129,12 +143,14 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
     const long long nruns = (long long)H * runs_per_row;
     const double f2 = (double)f * (double)f;
-    const bool vec = run_vec_ok(lab, W);
+    const bool vec = run_vec_ok(lab, depth, W);
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
         const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
         const int x1 = min(x0 + LGL_RUN, W);
         int16_t ids[LGL_RUN];
         if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
+        float dv[LGL_RUN];
+        load_run_depth(depth, W, y, x0, x1, vec, dv);
         int cur = 0;
         unsigned long long a = 0; long long sx = 0; double sd = 0.0, sr = 0.0; int bd = 0;
         const double dy = (double)y - (double)cy;
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                 if (a == 0) atomicMin(&s_first, (unsigned long long)y * W + x);
                 a++;
                 sx += x;
-                sd += (double)depth[(size_t)y * W + x];
+                sd += (double)dv[k < LGL_RUN ? k : 0];
                 const double dx = (double)x - (double)cx;
                 sr += sqrt(dx * dx + dy * dy + f2);
                 bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, c
     __syncthreads();
     const int shift = 8 * pass;
     const uint32_t himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
-    const bool vec = run_vec_ok(lab, W);
+    const bool vec = run_vec_ok(lab, depth, W);
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
     const long long nruns = (long long)H * runs_per_row;
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
@@ -224,11 +240,12 @@ __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, c
         const int x1 = min(x0 + LGL_RUN, W);
         int16_t ids[LGL_RUN];
         if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
+        float dv[LGL_RUN];
+        load_run_depth(depth, W, y, x0, x1, vec, dv);
         int cur_id = 0, cur_slot = -1, cur_bin = -1;
         uint32_t cnt = 0, cur_prefix = 0;
 #pragma unroll
         for (int k = 0; k < LGL_RUN; k++) {
-            const int x = x0 + k;
             int id = (int)ids[k];
             if (id <= 0) continue;
             if (id != cur_id) {
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, c
                 if (cur_slot < LGL_MAXL) cur_prefix = st[cur_slot].prefix;
             }
             if (cur_slot >= LGL_MAXL) continue;
-            const uint32_t key = f2key(depth[(size_t)y * W + x]);
+            const uint32_t key = f2key(dv[k]);
             if ((key & himask) != (cur_prefix & himask)) continue;
             const int bin = (int)((key >> shift) & 0xFFu);
             if (bin != cur_bin) {
