@@ -368,9 +368,11 @@ __global__ __launch_bounds__(256) void lgt_bn_stats_kernel(const float* __restri
     const float* xc = x + ((size_t)na * C + c) * HW;
     const size_t sn = (size_t)C * HW;
     float s = 0.0f;
+#pragma unroll 4
     for (int i = t; i < M; i += 256) s += xc[(size_t)(i / HW) * sn + i % HW];
     const float mu = block_sum(s, s_red) / (float)M;
     float v = 0.0f;
+#pragma unroll 4
     for (int i = t; i < M; i += 256) {
         const float d = xc[(size_t)(i / HW) * sn + i % HW] - mu;
         v += d * d;
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
     float sg = 0.0f, sb = 0.0f;
     if (!POOL) {
         const int HW = WI * WI, M = (nb - na) * HW;
+#pragma unroll 4
         for (int i = t; i < M; i += 256) {
             const size_t e = ((size_t)(na + i / HW) * C + c) * HW + i % HW;
             const float xh = (x[e] - mu) * rs;
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(256) void lgt_bn_bwd_reduce_kernel(const float* __r
     const float invM = 1.0f / (float)(N * WI * WI), mb = sb * invM, mg = sg * invM;
     if (!POOL) {
         const int HW = WI * WI, M = N * HW;
+#pragma unroll 4
         for (int i = t; i < M; i += 256) {
             const size_t e = ((size_t)(i / HW) * C + c) * HW + i % HW;
             const float xh = (x[e] - mu) * rs;
@@ -674,7 +678,9 @@ __global__ void lgt_relu_bwd_kernel(const float* __restrict__ dr, const float* _
     if (i < n) dz1[i] = z1[i] > 0.0f ? dr[i] : 0.0f;
 }
 
-// Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, 16 samples), the weight row held in registers (I <= 1024)
+// Y[n][o] = b[o] + sum_i X[n][i] W[o][i]; one wave per (o, kFcRows samples), the weight row held in registers (I <= 1024).
+// Four samples per wave: one dependent round of loads + shuffles per launch (16 per wave cost 18 us at batch 16).
+constexpr int kFcRows = 4;
 __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ Y, int N, int I,
                                                          int O) {
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(256) void lgt_fc_fwd_kernel(const float* __restrict
     for (int k = 0; k < 16; k++) w[k] = lane + 64 * k < I ? W[(size_t)o * I + lane + 64 * k] : 0.0f;
     const float bo = b[o];
     const int nk = (I + 63) / 64;
-    const int nb = blockIdx.y * 16, ne = min(N, nb + 16);
+    const int nb = blockIdx.y * kFcRows, ne = min(N, nb + kFcRows);
     for (int n = nb; n < ne; n += 4) {   // four independent samples at a time: their loads and shuffle chains overlap
         float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1254,10 +1260,10 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
             m = tr->ca_m;
         }
         const size_t nh = (size_t)N * hid, nf = (size_t)N * F;
-        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(hid, 4), cdiv(N, 16)), dim3(256), 0, s, m, tr->P_ + tr->ca_w1,
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(hid, 4), cdiv(N, kFcRows)), dim3(256), 0, s, m, tr->P_ + tr->ca_w1,
                            tr->P_ + tr->ca_b1, tr->ca_z1, N, F, hid);
         hipLaunchKernelGGL(lgt_relu_kernel, dim3(cdiv(nh, 256)), dim3(256), 0, s, tr->ca_z1, tr->ca_r, nh);
-        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(F, 4), cdiv(N, 16)), dim3(256), 0, s, tr->ca_r, tr->P_ + tr->ca_w2,
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(F, 4), cdiv(N, kFcRows)), dim3(256), 0, s, tr->ca_r, tr->P_ + tr->ca_w2,
                            tr->P_ + tr->ca_b2, tr->ca_z2, N, hid, F);
         hipLaunchKernelGGL(lgt_catt_gate_kernel, dim3(cdiv(nf, 256)), dim3(256), 0, s, tr->ca_z2, tr->gap, tr->ca_ca, tr->gap2, nf);
         pooled = tr->gap2;
@@ -1265,7 +1271,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     const float* fin = pooled;
     for (int k = 0; k < 4; k++) {
         TrainFc& f = tr->fc[k];
-        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(f.out, 4), cdiv(N, 16)), dim3(256), 0, s, fin, tr->P_ + f.w,
+        hipLaunchKernelGGL(lgt_fc_fwd_kernel, dim3(cdiv(f.out, 4), cdiv(N, kFcRows)), dim3(256), 0, s, fin, tr->P_ + f.w,
                            tr->P_ + f.b, k < 3 ? f.u : tr->logits, N, f.in, f.out);
         if (k < 3) {
             hipLaunchKernelGGL(lgt_bn1d_fwd_kernel, dim3(cdiv(f.out, 64)), dim3(64, kRG), 0, s, f.u, tr->P_ + f.g, tr->P_ + f.be,
