@@ -23,6 +23,56 @@ _FP = C.POINTER(C.c_float)
 _ATT = {"spatial": 0, "channel": 1, "hybrid": 2, "none": 3}   # include/leafgrasp.h LG_ATT_*
 
 
+class EarlyStopping:
+    """train_model.py:11-39, same constructor and step(): stop after `patience` epochs without an improvement of more than
+    `min_delta`; on stopping put the best epoch's weights back.  `model` is anything with state_dict() / load_state_dict()
+    (the reference passes its nn.Module, fit() passes the GraspTrainer)."""
+
+    def __init__(self, patience=15, min_delta=0.001, restore_best_weights=True):
+        self.patience, self.min_delta, self.restore_best_weights = patience, min_delta, restore_best_weights
+        self.counter, self.best_loss, self.best_epoch, self.best_weights = 0, None, None, None
+
+    def _snapshot(self, model):
+        return {k: (v.cpu().clone() if hasattr(v, "clone") else v) for k, v in model.state_dict().items()}
+
+    def step(self, val_loss, epoch, model):
+        if self.best_loss is None:
+            self.best_loss, self.best_epoch = val_loss, epoch
+            if self.restore_best_weights:
+                self.best_weights = self._snapshot(model)
+        elif val_loss > self.best_loss - self.min_delta:
+            self.counter += 1
+            if self.counter >= self.patience:
+                if self.restore_best_weights and self.best_weights is not None:
+                    model.load_state_dict(self.best_weights)
+                return True
+        else:
+            self.best_loss, self.best_epoch, self.counter = val_loss, epoch, 0
+            if self.restore_best_weights:
+                self.best_weights = self._snapshot(model)
+        return False
+
+
+class PlateauScheduler:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor, patience, min_lr) as the script configures it
+    (train_model.py:223-229; threshold 1e-4 relative, no cooldown, eps 1e-8) driving GraspTrainer.lr."""
+
+    def __init__(self, trainer, factor=0.5, patience=5, min_lr=1e-6, threshold=1e-4, eps=1e-8):
+        self.trainer, self.factor, self.patience, self.min_lr, self.threshold, self.eps = trainer, factor, patience, min_lr, threshold, eps
+        self.best, self.num_bad_epochs = float("inf"), 0
+
+    def step(self, metric):
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad_epochs = metric, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.trainer.lr * self.factor, self.min_lr)
+            if self.trainer.lr - new_lr > self.eps:
+                self.trainer.lr = new_lr
+            self.num_bad_epochs = 0
+
+
 def normalize_data(depth_patches, score_patches):
     """train_model.py:41-62 -- global z-score of the depth patches, per-channel z-score of the score patches."""
     depth_mean, depth_std = depth_patches.mean(), depth_patches.std()
@@ -175,17 +225,19 @@ class GraspTrainer:
         return out
 
     def load_state_dict(self, sd, optimizer_state=None):
-        """Module state dict (reference key names); optimizer_state = {'exp_avg': {key: t}, 'exp_avg_sq': {...}, 'step': n}."""
+        """Module state dict (reference key names).  optimizer_state = {'exp_avg': {key: t}, 'exp_avg_sq': {...}, 'step': n}
+        replaces the Adam state as well; None leaves it as it is (a fresh trainer starts from zeros / step 0)."""
         for k, shape in self._params + self._buffers:
             if k not in sd or tuple(sd[k].shape) != tuple(shape):
                 raise ValueError(f"state_dict entry {k!r} missing or of wrong shape (expected {shape})")
         p, b = self._flat(sd, self._params), self._flat(sd, self._buffers)
-        m = v = None
-        step = 0
         if optimizer_state is not None:
             m = self._flat(optimizer_state["exp_avg"], self._params)
             v = self._flat(optimizer_state["exp_avg_sq"], self._params)
             step = int(optimizer_state["step"])
+        else:   # nn.Module.load_state_dict leaves the optimizer alone: keep the moments and the step count
+            cur = self._get(m=True, v=True)
+            m, v, step = cur["exp_avg"], cur["exp_avg_sq"], int(cur["step"])
         nbt = [sd[k] for k in sd if k.endswith("num_batches_tracked")]
         self.num_batches_tracked = int(nbt[0]) if nbt else 0
         self._check(lib.lg_train_set_state(self._h, p.ctypes.data_as(_FP), b.ctypes.data_as(_FP),
@@ -354,7 +406,9 @@ class GraspTrainer:
         w[tr_y == 0] = 1.0 / pos_weight
         from .grasp_point_selector import GraspPointSelector
         sel = GraspPointSelector(self.device)
-        best_val, best_epoch, best_state, counter, sched_bad, sched_best = float("inf"), None, None, 0, 0, float("inf")
+        best_val = float("inf")
+        early_stopping = EarlyStopping(patience=patience, min_delta=min_delta, restore_best_weights=True)
+        scheduler = PlateauScheduler(self, factor=sched_factor, patience=sched_patience, min_lr=min_lr)
         train_losses, val_losses, metrics_history = [], [], []
         for epoch in range(num_epochs):
             idx = torch.multinomial(w.cpu(), n_tr, replacement=True, generator=gen).to(self.device)
@@ -375,14 +429,7 @@ class GraspTrainer:
             val_losses.append(val_loss)
             metrics = analyze_predictions(vl, va_y)
             metrics_history.append(metrics)
-            # ReduceLROnPlateau (mode 'min', threshold 1e-4 relative)
-            if val_loss < sched_best * (1.0 - 1e-4):
-                sched_best, sched_bad = val_loss, 0
-            else:
-                sched_bad += 1
-                if sched_bad > sched_patience:
-                    self.lr = max(self.lr * sched_factor, min_lr)
-                    sched_bad = 0
+            scheduler.step(val_loss)
             if log:
                 log(f"Epoch [{epoch + 1}/{num_epochs}]: train {train_losses[-1]:.4f} val {val_loss:.4f} "
                     f"acc {100.0 * correct / max(n_tr, 1):.2f}% lr {self.lr:.6f} f1 {metrics['f1_score']:.2f}%")
@@ -396,16 +443,9 @@ class GraspTrainer:
                                 "normalization_stats": normalization_stats, "train_losses": train_losses,
                                 "val_losses": val_losses, "metrics_history": metrics_history},
                                os.path.join(save_dir, "best_model.pth"))
-            # EarlyStopping.step (:21-39)
-            if best_epoch is None or not (val_loss > es_best - min_delta):
-                es_best, best_epoch, counter = val_loss, epoch, 0
-                best_state = (self.state_dict(), self.optimizer_state())
-            else:
-                counter += 1
-                if counter >= patience:
-                    self.load_state_dict(best_state[0], best_state[1])
-                    if log:
-                        log(f"Early stopping triggered! Best epoch was {best_epoch + 1}")
-                    break
+            if early_stopping.step(val_loss, epoch, self):   # restores the best epoch's module state (:21-39)
+                if log:
+                    log(f"Early stopping triggered! Best epoch was {early_stopping.best_epoch + 1}")
+                break
         return {"train_losses": train_losses, "val_losses": val_losses, "metrics_history": metrics_history,
-                "best_val_loss": best_val, "best_epoch": best_epoch}
+                "best_val_loss": best_val, "best_epoch": early_stopping.best_epoch}

@@ -69,3 +69,63 @@ for att, filt, n in CASES:
     out[f"{tag}_nbt"] = np.array(int(sd["encoder.0.1.num_batches_tracked"]))
 np.savez_compressed(os.path.join(HERE, "train_vectors.npz"), **out)
 print({k: (v.tolist() if v.size < 4 else v.reshape(-1)[:3].tolist()) for k, v in out.items() if "sample" not in k and "pick" not in k and "names" not in k})
+
+# ---- host-side helpers of the training script: EarlyStopping (train_model.py:11-39), normalize_data (:41-62),
+# analyze_predictions (:64-99), run from the reference file itself (rospy / cv2 replaced by import-only stubs as in make_golden.py)
+from make_golden import _install_stubs  # noqa: E402
+
+_install_stubs()
+sys.path.insert(0, "/root/reference/scripts")
+tm = _load_by_path("ref_train_model", "/root/reference/scripts/train_model.py")
+
+
+class _Model:
+    def __init__(self):
+        self.w = torch.zeros(1)
+
+    def state_dict(self):
+        return {"w": self.w.clone()}
+
+    def load_state_dict(self, sd):
+        self.w = sd["w"].clone()
+
+
+hout = {}
+rng = np.random.default_rng(7)
+seqs, stops, bests, restored = [], [], [], []
+for s_i in range(16):
+    n = 60
+    base = 1.0 / (1.0 + 0.15 * np.arange(n)) + 0.3
+    noise = rng.normal(0, 0.004 * (1 + s_i % 4), n)
+    seq = base + noise
+    if s_i % 3 == 0:
+        seq[20:] = seq[20] + np.abs(rng.normal(0, 0.0008, n - 20))      # plateau within min_delta
+    es = tm.EarlyStopping(patience=15 if s_i % 2 == 0 else 5, min_delta=0.001, restore_best_weights=True)
+    m = _Model()
+    stop = -1
+    for epoch, v in enumerate(seq):
+        m.w = torch.tensor([float(epoch)])
+        if es.step(float(v), epoch, m):
+            stop = epoch
+            break
+    seqs.append(seq)
+    stops.append(stop)
+    bests.append([es.best_epoch, es.best_loss])
+    restored.append(float(m.w[0]))
+hout["es_seqs"], hout["es_stop"], hout["es_best"], hout["es_restored"] = np.array(seqs), np.array(stops), np.array(bests), np.array(restored)
+d = torch.from_numpy(rng.random((6, 1, 8, 8)).astype(np.float32) * 0.4 + 0.3)      # any spatial size: global / per-channel statistics
+sc = torch.from_numpy((rng.random((6, 7, 8, 8)) * np.arange(1, 8)[None, :, None, None]).astype(np.float32))
+nd = tm.normalize_data(d, sc)
+hout["nd_depth_in"], hout["nd_score_in"] = d.numpy(), sc.numpy()
+hout["nd_depth"], hout["nd_score"] = nd["depth_patches"].numpy(), nd["score_patches"].numpy()
+hout["nd_stats"] = np.concatenate([nd["stats"]["depth_mean"].reshape(-1).numpy(), nd["stats"]["depth_std"].reshape(-1).numpy(),
+                                   nd["stats"]["score_mean"].reshape(-1).numpy(), nd["stats"]["score_std"].reshape(-1).numpy()])
+outs = torch.from_numpy(rng.normal(0.3, 1.0, (40, 1)).astype(np.float32))
+labs = torch.from_numpy((rng.random(40) < 0.45).astype(np.float32))
+ap = tm.analyze_predictions(outs, labs)
+hout["ap_outputs"], hout["ap_labels"] = outs.numpy(), labs.numpy()
+hout["ap_metrics"] = np.array([ap["positive_accuracy"], ap["negative_accuracy"], ap["precision"], ap["recall"], ap["f1_score"],
+                               ap["confusion_matrix"]["true_positive"], ap["confusion_matrix"]["false_positive"],
+                               ap["confusion_matrix"]["false_negative"], ap["confusion_matrix"]["true_negative"]], np.float64)
+np.savez_compressed(os.path.join(HERE, "train_host_vectors.npz"), **hout)
+print("host helpers:", hout["es_stop"].tolist(), hout["ap_metrics"].tolist())

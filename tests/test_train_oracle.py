@@ -138,3 +138,70 @@ def test_prepare_features_follows_the_training_script():
     torch.testing.assert_close(f[:, 1], data["mask_patches"])
     torch.testing.assert_close(f[:, 2:], n["score_patches"])
     assert set(stats) == {"depth_mean", "depth_std", "score_mean", "score_std"}
+
+
+def test_host_helpers_match_the_reference_training_script():
+    """EarlyStopping (train_model.py:11-39), normalize_data (:41-62) and analyze_predictions (:64-99) against vectors produced
+    by the reference's own functions (tests/golden/make_golden_train.py)."""
+    from leafgrasp_amd.trainer import EarlyStopping, analyze_predictions, normalize_data
+    hv = np.load(os.path.join(HERE, "golden", "train_host_vectors.npz"))
+
+    class Model:
+        def __init__(self):
+            self.w = torch.zeros(1)
+
+        def state_dict(self):
+            return {"w": self.w.clone()}
+
+        def load_state_dict(self, sd):
+            self.w = sd["w"].clone()
+    for i, seq in enumerate(hv["es_seqs"]):
+        es = EarlyStopping(patience=15 if i % 2 == 0 else 5, min_delta=0.001, restore_best_weights=True)
+        m, stop = Model(), -1
+        for epoch, v in enumerate(seq):
+            m.w = torch.tensor([float(epoch)])
+            if es.step(float(v), epoch, m):
+                stop = epoch
+                break
+        assert stop == int(hv["es_stop"][i]) and es.best_epoch == int(hv["es_best"][i][0]) and es.best_loss == hv["es_best"][i][1]
+        assert float(m.w[0]) == hv["es_restored"][i]
+    assert (hv["es_stop"] >= 0).sum() >= 5 and (hv["es_stop"] < 0).sum() >= 3     # both outcomes are in the fixture
+    nd = normalize_data(torch.from_numpy(hv["nd_depth_in"]), torch.from_numpy(hv["nd_score_in"]))
+    np.testing.assert_array_equal(nd["depth_patches"].numpy(), hv["nd_depth"])
+    np.testing.assert_array_equal(nd["score_patches"].numpy(), hv["nd_score"])
+    st = nd["stats"]
+    np.testing.assert_array_equal(np.concatenate([st["depth_mean"].reshape(-1).numpy(), st["depth_std"].reshape(-1).numpy(),
+                                                  st["score_mean"].reshape(-1).numpy(), st["score_std"].reshape(-1).numpy()]),
+                                  hv["nd_stats"])
+    ap = analyze_predictions(torch.from_numpy(hv["ap_outputs"]), torch.from_numpy(hv["ap_labels"]))
+    got = [ap["positive_accuracy"], ap["negative_accuracy"], ap["precision"], ap["recall"], ap["f1_score"],
+           ap["confusion_matrix"]["true_positive"], ap["confusion_matrix"]["false_positive"],
+           ap["confusion_matrix"]["false_negative"], ap["confusion_matrix"]["true_negative"]]
+    np.testing.assert_array_equal(np.array(got, np.float64), hv["ap_metrics"])
+
+
+def test_plateau_scheduler_equals_torch():
+    """PlateauScheduler against torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor=0.5, patience=5, min_lr=1e-6)
+    (train_model.py:223-229) on seeded loss sequences."""
+    from leafgrasp_amd.trainer import PlateauScheduler
+
+    class T:
+        lr = 0.0005
+    rng = np.random.default_rng(4)
+    reduced = 0
+    for trial in range(8):
+        seq = 1.0 / (1.0 + 0.2 * np.arange(80)) + 0.2 + rng.normal(0, 0.003 * (1 + trial % 3), 80)
+        if trial % 2:
+            seq[15:] = seq[15]
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=0.0005)
+        ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=5, min_lr=1e-6)
+        t = T()
+        t.lr = 0.0005
+        mine = PlateauScheduler(t, factor=0.5, patience=5, min_lr=1e-6)
+        for v in seq:
+            ref.step(float(v))
+            mine.step(float(v))
+            assert t.lr == opt.param_groups[0]["lr"]
+        reduced += t.lr < 0.0005
+    assert reduced >= 4      # the plateau sequences do reduce the rate
