@@ -449,3 +449,35 @@ class GraspTrainer:
                 break
         return {"train_losses": train_losses, "val_losses": val_losses, "metrics_history": metrics_history,
                 "best_val_loss": best_val, "best_epoch": early_stopping.best_epoch}
+
+
+def train_grasp_model(data_path=None, save_dir=None, device="cuda:0", num_epochs=150, log=print, **trainer_kwargs):
+    """scripts/train_model.py::train_grasp_model (:155-395) on this path: torch.manual_seed(42), load
+    ~/leaf_grasp_output/ml_training_data/training_data.pt (EnhancedGraspDataCollector's file; loaded with weights_only=True),
+    normalise, 80/20 split, weighted sampling, Adam / ReduceLROnPlateau / EarlyStopping, best_model.pth + final_model.pth in
+    ~/leaf_grasp_output/ml_models.  The plots of the script (:101-153) are not produced.  Returns the history dict of fit()."""
+    torch.manual_seed(42)
+    data_path = data_path or os.path.expanduser("~/leaf_grasp_output/ml_training_data/training_data.pt")
+    save_dir = save_dir or os.path.expanduser("~/leaf_grasp_output/ml_models")
+    data = torch.load(data_path, map_location="cpu", weights_only=True)
+    if log:
+        log(f"Loaded {len(data['labels'])} samples")
+    features, labels, stats = prepare_features(data)
+    if log:
+        log(f"Combined features shape: {tuple(features.shape)}")
+    trainer = GraspTrainer(torch.device(device), **trainer_kwargs)
+    hist = trainer.fit(features, labels, num_epochs=num_epochs, save_dir=save_dir, normalization_stats=stats, log=log)
+    torch.save({"epoch": len(hist["val_losses"]) - 1, "model_state_dict": trainer.state_dict(),
+                "optimizer_state_dict": trainer.torch_optimizer_state_dict(),
+                "val_loss": hist["val_losses"][-1] if hist["val_losses"] else None,
+                "metrics": hist["metrics_history"][-1] if hist["metrics_history"] else None,
+                "normalization_stats": stats, "train_losses": hist["train_losses"], "val_losses": hist["val_losses"],
+                "metrics_history": hist["metrics_history"]}, os.path.join(save_dir, "final_model.pth"))
+    if log:
+        log(f"Best validation loss: {hist['best_val_loss']:.4f}")
+    hist["trainer"] = trainer
+    return hist
+
+
+if __name__ == "__main__":
+    train_grasp_model()

@@ -308,3 +308,30 @@ def test_data_parallel_step_two_ranks(tmp_path):
     expect = p0 - (0.0005 / 0.1) * (m / (np.sqrt(v) / np.sqrt(0.001) + 1e-8))
     np.testing.assert_allclose(r0["exp_avg"], m, rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(r0["params"], expect, rtol=1e-5, atol=2e-6)
+
+
+def test_train_grasp_model_entry_point(tmp_path):
+    """scripts/train_model.py::train_grasp_model on a small training_data.pt in the data collector's layout: the file is
+    read (weights_only), features prepared, two epochs run, best_model.pth / final_model.pth written with the reference's
+    checkpoint keys and readable by GraspPointSelector.load_ml_model."""
+    import leafgrasp_amd as L
+    from leafgrasp_amd.trainer import train_grasp_model
+    rng = np.random.default_rng(5)
+    n = 80
+    labels = (rng.random(n) < 0.45).astype(np.int64)
+    scores = rng.random((n, 7, 32, 32)).astype(np.float32)
+    scores[labels == 1, 0] += 0.5
+    data = {"depth_patches": torch.from_numpy(rng.random((n, 32, 32)).astype(np.float32) * 0.3 + 0.3),
+            "mask_patches": torch.from_numpy((rng.random((n, 32, 32)) > 0.3).astype(np.float32)),
+            "score_patches": torch.from_numpy(scores), "labels": torch.from_numpy(labels)}
+    torch.save(data, tmp_path / "training_data.pt")
+    hist = train_grasp_model(str(tmp_path / "training_data.pt"), str(tmp_path / "models"), device=DEV, num_epochs=2, log=None)
+    assert len(hist["train_losses"]) == 2 and np.isfinite(hist["best_val_loss"])
+    for name in ("best_model.pth", "final_model.pth"):
+        ck = torch.load(tmp_path / "models" / name, map_location="cpu", weights_only=True)
+        assert {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "metrics", "normalization_stats",
+                "train_losses", "val_losses", "metrics_history"} <= set(ck)
+        assert set(ck["normalization_stats"]) == {"depth_mean", "depth_std", "score_mean", "score_std"}
+    sel = L.GraspPointSelector(torch.device(DEV), load_model=False)
+    sel.load_ml_model(str(tmp_path / "models" / "best_model.pth"))
+    assert sel.ml_predictor is not None

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--torch-baseline", action="store_true",
                     help="also time the same step written with torch.nn modules + torch.optim.Adam on the same device "
                          "(PyTorch-ROCm eager: MIOpen / rocBLAS kernels) -- what the reference's script would run here")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="also time the stock-torch step on the host cores (batch 16, a few steps)")
     a = ap.parse_args()
     filters = tuple(int(v) for v in a.filters.split(","))
     dev = torch.device("cuda:0")
@@ -71,6 +73,10 @@ def main():
         del tr
         if a.torch_baseline:
             print(json.dumps(torch_eager(n, filters, x, y, a.steps, a.warmup)), flush=True)
+        if a.cpu_baseline and n == 16:
+            r = torch_eager(n, filters, x.cpu(), y.cpu(), 5, 1)
+            r["device"], r["threads"] = "cpu", torch.get_num_threads()
+            print(json.dumps(r), flush=True)
 
 
 def torch_eager(n, filters, x, y, steps, warmup):
@@ -113,7 +119,8 @@ def torch_eager(n, filters, x, y, steps, warmup):
         return loss
     for _ in range(warmup + 3):
         step()
-    torch.cuda.synchronize()
+    if x.is_cuda:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
