@@ -961,7 +961,7 @@ int dalloc(lg_trainer* tr, float** p, size_t floats) {
 }
 
 // workgroups of a shape below which the next smaller shape is launched
-constexpr int kSmallConvBelow = 512, kSplitConvBelow = 256;
+int kSmallConvBelow = 512, kSplitConvBelow = 256;   // LG_TRAIN_CONV_SMALL / LG_TRAIN_CONV_SPLIT override (tuning runs)
 int conv_tiles(int wi, int N, int tile);
 void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N, int CI,
                  int CO) {
@@ -1119,6 +1119,8 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     A(&sd, 2);
     tr->seed_dev = (uint64_t*)sd;
     if (const char* e = getenv("LG_TRAIN_GRAPH")) tr->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("LG_TRAIN_CONV_SMALL")) kSmallConvBelow = atoi(e);
+    if (const char* e = getenv("LG_TRAIN_CONV_SPLIT")) kSplitConvBelow = atoi(e);
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream_w, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     for (int k = 0; k < 8 && rc == LG_OK; k++)
