@@ -960,8 +960,9 @@ int dalloc(lg_trainer* tr, float** p, size_t floats) {
     return LG_OK;
 }
 
-// workgroups of a shape below which the next smaller shape is launched
-int kSmallConvBelow = 512, kSplitConvBelow = 256;   // LG_TRAIN_CONV_SMALL / LG_TRAIN_CONV_SPLIT override (tuning runs)
+// workgroups of a shape below which the next smaller shape is launched: one workgroup per CU is where the larger tile
+// stops paying (swept over batches 16..512: 256 / 256 is the best pair, e.g. batch 256 3.30 ms vs 3.47 with 512 / 256)
+int kSmallConvBelow = 256, kSplitConvBelow = 256;   // LG_TRAIN_CONV_SMALL / LG_TRAIN_CONV_SPLIT override (tuning runs)
 int conv_tiles(int wi, int N, int tile);
 void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N, int CI,
                  int CO) {
