@@ -23,6 +23,10 @@ from .grasp_point_selector import _device_index
 
 _VP = C.c_void_p
 _MAX_LEAVES = 64
+# numpy view of lg_leaf_stat (include/leafgrasp.h; ctypes mirror: _lib.LgLeafStat)
+_STAT_DTYPE = np.dtype([("id", "<i4"), ("area", "<i4"), ("touches_border", "<i4"), ("pad_", "<i4"), ("sum_x", "<f8"),
+                        ("sum_y", "<f8"), ("sum_depth", "<f8"), ("sum_ray", "<f8"), ("median_depth", "<f4"), ("pad2_", "<f4")])
+assert _STAT_DTYPE.itemsize == C.sizeof(LgLeafStat)
 
 
 def pareto_mask_max(scores):
@@ -121,19 +125,24 @@ class OptimalLeafSelector:
                                                    stats, _MAX_LEAVES, n, ext, status,
                                                    _VP(torch.cuda.current_stream(self.device).cuda_stream)),
                   "lg_leaf_stats_batch")
+        # one structured view over the whole result instead of a ctypes attribute read per field (8 fields x ~8 leaves x B
+        # frames were 2 of the 3 ms of host time per 128 frames)
+        arr = np.frombuffer(stats, dtype=_STAT_DTYPE).reshape(B, _MAX_LEAVES)
+        nn, st, ex = np.frombuffer(n, np.int32), np.frombuffer(status, np.int32), np.frombuffer(ext, np.int32).reshape(B, 4).tolist()
         out = []
         for b in range(B):
-            if status[b] != 0:
+            if st[b] != 0:
                 out.append(None)
                 continue
-            fs = []
-            for i in range(n[b]):
-                s = stats[b * _MAX_LEAVES + i]
-                fs.append(dict(id=int(s.id), area=int(s.area), touches_border=bool(s.touches_border),
-                               sum_x=float(s.sum_x), sum_y=float(s.sum_y), sum_depth=float(s.sum_depth),
-                               sum_ray=float(s.sum_ray), median_depth=np.float32(s.median_depth)))
-            e = ext[4 * b:4 * b + 4]
-            out.append((fs, ((int(e[0]), int(e[1])), (int(e[2]), int(e[3]))), (H, W)))
+            a = arr[b, :nn[b]]
+            med = a["median_depth"]
+            fs = [dict(id=i, area=ar, touches_border=bool(tb), sum_x=sx, sum_y=sy, sum_depth=sd, sum_ray=sr, median_depth=med[k])
+                  for k, (i, ar, tb, sx, sy, sd, sr) in enumerate(zip(a["id"].tolist(), a["area"].tolist(),
+                                                                    a["touches_border"].tolist(), a["sum_x"].tolist(),
+                                                                    a["sum_y"].tolist(), a["sum_depth"].tolist(),
+                                                                    a["sum_ray"].tolist()))]
+            e = ex[b]
+            out.append((fs, ((e[0], e[1]), (e[2], e[3])), (H, W)))
         return out
 
     def select_optimal_leaves_batch(self, mask_tensors, depth_tensors):
