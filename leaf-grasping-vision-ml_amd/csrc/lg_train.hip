@@ -912,6 +912,7 @@ struct lg_trainer {
     hipStream_t stream = nullptr, stream_w = nullptr;   // main chain; backward-weights branch
     hipEvent_t ev_dx[8] = {}, ev_wg[8] = {};
     uint64_t* seed_dev = nullptr;
+    int conv_small_below = 256, conv_split_below = 256;   // convolution shape thresholds (launch_conv)
     bool use_graph = false;                      // LG_TRAIN_GRAPH=1: replay the step as a captured graph (measured: no gain)
     std::map<uint64_t, hipGraphExec_t> graphs;   // key: N, masks drawn on the device, optimizer applied
     int64_t steps = 0;
@@ -962,13 +963,13 @@ int dalloc(lg_trainer* tr, float** p, size_t floats) {
 
 // workgroups of a shape below which the next smaller shape is launched: one workgroup per CU is where the larger tile
 // stops paying (swept over batches 16..512: 256 / 256 is the best pair, e.g. batch 256 3.30 ms vs 3.47 with 512 / 256)
-int kSmallConvBelow = 256, kSplitConvBelow = 256;   // LG_TRAIN_CONV_SMALL / LG_TRAIN_CONV_SPLIT override (tuning runs)
+// (the thresholds live in the trainer: conv_small_below / conv_split_below, LG_TRAIN_CONV_SMALL / LG_TRAIN_CONV_SPLIT for tuning runs)
 int conv_tiles(int wi, int N, int tile);
-void launch_conv(int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out, int N, int CI,
-                 int CO) {
+void launch_conv(const lg_trainer* tr, int wi, hipStream_t s, const float* in, const float* wp, const float* bias, float* out,
+                 int N, int CI, int CO) {
     const unsigned cb = (unsigned)((CO + 63) / 64), cb32 = (unsigned)((CO + 31) / 32);
-    const bool small = conv_tiles(wi, N, 256) * (int)cb < kSmallConvBelow;
-    const bool split = conv_tiles(wi, N, 64) * (int)cb < kSplitConvBelow && CI >= 32;
+    const bool small = conv_tiles(wi, N, 256) * (int)cb < tr->conv_small_below;
+    const bool split = conv_tiles(wi, N, 64) * (int)cb < tr->conv_split_below && CI >= 32;
 #define LGT_CONV(W)                                                                                                    \
     if (split)                                                                                                         \
         hipLaunchKernelGGL((lgt_conv_kernel<W, 1, 1, 1, 4, 8>), dim3(conv_tiles(W, N, 32), cb32), dim3(256), 0, s, in, wp,  \
@@ -1120,8 +1121,8 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     A(&sd, 2);
     tr->seed_dev = (uint64_t*)sd;
     if (const char* e = getenv("LG_TRAIN_GRAPH")) tr->use_graph = atoi(e) != 0;
-    if (const char* e = getenv("LG_TRAIN_CONV_SMALL")) kSmallConvBelow = atoi(e);
-    if (const char* e = getenv("LG_TRAIN_CONV_SPLIT")) kSplitConvBelow = atoi(e);
+    if (const char* e = getenv("LG_TRAIN_CONV_SMALL")) tr->conv_small_below = atoi(e);
+    if (const char* e = getenv("LG_TRAIN_CONV_SPLIT")) tr->conv_split_below = atoi(e);
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     if (rc == LG_OK && hipStreamCreateWithFlags(&tr->stream_w, hipStreamNonBlocking) != hipSuccess) rc = LG_ERR_HIP;
     for (int k = 0; k < 8 && rc == LG_OK; k++)
@@ -1232,7 +1233,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     // ---------------- forward
     const float* a = tr->xin;
     for (auto& L : tr->layers) {
-        launch_conv(L.wi, s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
+        launch_conv(tr, L.wi, s, a, L.wpf, tr->P_ + L.b, L.x, N, L.ci, L.co);
         const int S = bn_chunks(N, L.co, L.wi * L.wi), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         hipLaunchKernelGGL(lgt_bn_stats_kernel, dim3(L.co, Sy), dim3(256), 0, s, L.x, N, L.co, L.wi * L.wi, chunk, eps, mom,
                            tr->bn_part, tr->mean + L.st, tr->rstd + L.st, tr->B + L.rm, tr->B + L.rv);
@@ -1371,7 +1372,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, sw, tr->partial, Sw, L.ci, L.co, tr->G + L.w);
         TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
         if (li > 0) {   // backward-data: a convolution of dX with the mirrored, channel-swapped weights
-            launch_conv(L.wi, s, dXl, L.wpd, (const float*)nullptr, tr->dA[cur ^ 1], N, L.co, L.ci);
+            launch_conv(tr, L.wi, s, dXl, L.wpd, (const float*)nullptr, tr->dA[cur ^ 1], N, L.co, L.ci);
             cur ^= 1;
         }
     }
