@@ -240,47 +240,51 @@ __global__ __launch_bounds__(kWgThreads, 2) void lgt_wgrad_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[k][r] = 0.0f;
 
-    // tile-invariant part of the source offsets (relative to sample n0, row y0); kNever: the slot always loads zero
-    constexpr int kNever = -2147483647 - 1;
+    // tile-invariant part of the source offsets (relative to sample n0, row y0) and, packed four to a register, a class byte
+    // per slot: bit 0 = never loads (padding slot, channel or column outside), bit 1 = top halo row (outside the image when
+    // the tile starts at row 0), bit 2 = bottom halo row (outside when the tile ends at the last row), bits 4-7 = sample
+    // within the tile.  Per tile a wave-uniform mask says which classes are dead: two VALU per slot decide the source.
     int rel_d[NSD], rel_i[NSI];
-    unsigned meta_i[(NSI + 3) / 4], meta_d[(NSD + 3) / 4];   // per slot: (sample within the tile) << 4 | halo row
+    unsigned cls_i[(NSI + 3) / 4], cls_d[(NSD + 3) / 4];
 #pragma unroll
-    for (int j = 0; j < (NSI + 3) / 4; j++) meta_i[j] = 0;
+    for (int j = 0; j < (NSI + 3) / 4; j++) cls_i[j] = 0;
 #pragma unroll
-    for (int j = 0; j < (NSD + 3) / 4; j++) meta_d[j] = 0;
+    for (int j = 0; j < (NSD + 3) / 4; j++) cls_d[j] = 0;
 #pragma unroll
     for (int j = 0; j < NSD; j++) {
         const int idx = t + NT * j, co = idx / SD, q = idx % SD;
         const int ts = q / (T::TR * WI), row = (q / WI) % T::TR, x = q % WI;
         const bool ok = idx < 64 * SD && q < kWgTile && co0 + co < CO;
-        rel_d[j] = ok ? ((ts * CO + co0 + co) * WI + row) * WI + x : kNever;
-        meta_d[j >> 2] |= (unsigned)(ts << 4) << (8 * (j & 3));
+        rel_d[j] = ok ? ((ts * CO + co0 + co) * WI + row) * WI + x : 0;
+        cls_d[j >> 2] |= (unsigned)((ok ? 0 : 1) | (ts << 4)) << (8 * (j & 3));
     }
 #pragma unroll
     for (int j = 0; j < NSI; j++) {
         const int idx = t + NT * j, ci = idx / SI, r = idx % SI;
         const int ts = r / (T::TH * T::TW), ry = (r / T::TW) % T::TH, rx = r % T::TW;
         const bool ok = idx < 32 * SI && r < T::PLANE && ci0 + ci < CI && rx >= 1 && rx <= WI;
-        rel_i[j] = ok ? ((ts * CI + ci0 + ci) * WI + ry - 1) * WI + rx - 1 : kNever;
-        meta_i[j >> 2] |= (unsigned)((ts << 4) | ry) << (8 * (j & 3));
+        rel_i[j] = ok ? ((ts * CI + ci0 + ci) * WI + ry - 1) * WI + rx - 1 : 0;
+        cls_i[j >> 2] |= (unsigned)((ok ? 0 : 1) | (ry == 0 ? 2 : 0) | (ry == T::TH - 1 ? 4 : 0) | (ts << 4)) << (8 * (j & 3));
     }
     auto issue_tile = [&](int tile, int stage) {
         float* sb = s_buf + stage * BUF;
         const int n0 = (tile / T::BANDS) * T::TS, y0 = (tile % T::BANDS) * T::TR;
         const float* d0 = dx + ((size_t)n0 * CO * WI + y0) * WI;
         const float* a0 = a + ((size_t)n0 * CI * WI + y0) * WI;
+        const unsigned dead = 1u | (y0 == 0 ? 2u : 0u) | (y0 + T::TR >= WI ? 4u : 0u);   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NSD; j++) {
-            const int ts = (meta_d[j >> 2] >> (8 * (j & 3) + 4)) & 15;
-            const float* src = (rel_d[j] != kNever && n0 + ts < N) ? d0 + rel_d[j] : lgt_zero_pad;
+            bool off = (cls_d[j >> 2] & (1u << (8 * (j & 3)))) != 0;
+            if (T::TS > 1) off = off || n0 + (int)((cls_d[j >> 2] >> (8 * (j & 3) + 4)) & 15u) >= N;
+            const float* src = off ? lgt_zero_pad : d0 + rel_d[j];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sb + NT * j + 64 * wave), 4, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NSI; j++) {
-            const unsigned m = (meta_i[j >> 2] >> (8 * (j & 3))) & 255u;
-            const int gy = y0 - 1 + (int)(m & 15u);
-            const float* src = (rel_i[j] != kNever && n0 + (int)(m >> 4) < N && gy >= 0 && gy < WI) ? a0 + rel_i[j] : lgt_zero_pad;
+            bool off = (cls_i[j >> 2] & (dead << (8 * (j & 3)))) != 0;
+            if (T::TS > 1) off = off || n0 + (int)((cls_i[j >> 2] >> (8 * (j & 3) + 4)) & 15u) >= N;
+            const float* src = off ? lgt_zero_pad : a0 + rel_i[j];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sb + NT * (NSD + j) + 64 * wave), 4, 0, 0);
         }
