@@ -33,7 +33,7 @@ def pareto_mask_max(scores):
     """paretoset(scores, sense=['max']*k): non-dominated rows, first of identical rows kept
     (paretoset 1.2.3 is not installed; leaf_scorer.py:158,163).  Plain-Python comparisons on the float64 values (the
     per-frame host cost of the batched path is this function and its caller, not the device passes)."""
-    rows = np.asarray(scores, np.float64).tolist()
+    rows = scores if isinstance(scores, list) else np.asarray(scores, np.float64).tolist()   # lists of Python floats as they are
     n = len(rows)
     keep = np.ones(n, bool)
     for i in range(n):
@@ -212,7 +212,8 @@ class OptimalLeafSelector:
                     visibility_score = 1.0 - d / math.sqrt((W / 2) ** 2 + (H / 2) ** 2)
                 candidates.append({
                     "leaf_id": s["id"],
-                    "scores": np.array([clutter_score, distance_score, visibility_score], dtype=np.float64),
+                    # Python floats: the same IEEE doubles as the reference's float64 array, without an ndarray per leaf
+                    "scores": (float(clutter_score), float(distance_score), float(visibility_score)),
                     "raw_scores": {"clutter": clutter_score, "distance": mean_distance, "visibility": visibility_score},
                     "is_tall": s["id"] in tall_leaves,
                     "centroid": centroid,
@@ -223,13 +224,11 @@ class OptimalLeafSelector:
             try:
                 tall_c = [c for c in candidates if c["is_tall"]]
                 reg_c = [c for c in candidates if not c["is_tall"]]
-                if tall_c:  # :150-160
-                    scores = np.stack([c["scores"] for c in tall_c]) * 1.1
-                    pm = pareto_mask_max(scores)
+                if tall_c:  # :150-160 (scores * 1.1: the same double products as the array expression)
+                    pm = pareto_mask_max([[v * 1.1 for v in c["scores"]] for c in tall_c])
                     pareto = [c for i, c in enumerate(tall_c) if pm[i]]
                 else:
-                    scores = np.stack([c["scores"] for c in reg_c])
-                    pm = pareto_mask_max(scores)
+                    pm = pareto_mask_max([list(c["scores"]) for c in reg_c])
                     pareto = [c for i, c in enumerate(reg_c) if pm[i]]
                 if not pareto:
                     pareto = tall_c if tall_c else reg_c
@@ -242,13 +241,15 @@ class OptimalLeafSelector:
                     if ws > best_score:
                         best_score, best_leaf = ws, c["leaf_id"]
                 if return_debug:
+                    for c in candidates:
+                        c["scores"] = np.array(c["scores"], dtype=np.float64)
                     return best_leaf, dict(candidates=candidates, tall=tall_leaves, extrema=(min_global, max_global),
                                            depth_list=depth_list)
                 return best_leaf
             except Exception as e:  # noqa: BLE001  (:198-202)
                 logerr(f"Error in Pareto optimization: {str(e)}")
                 if candidates:
-                    return max(candidates, key=lambda x: np.mean(x["scores"]))["leaf_id"]
+                    return max(candidates, key=lambda x: np.mean(np.array(x["scores"])))["leaf_id"]
                 return None
         except Exception as e:  # noqa: BLE001  (:201-203)
             logerr(f"Error in leaf selection: {str(e)}")
