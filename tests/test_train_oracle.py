@@ -205,3 +205,69 @@ def test_plateau_scheduler_equals_torch():
             assert t.lr == opt.param_groups[0]["lr"]
         reduced += t.lr < 0.0005
     assert reduced >= 4      # the plateau sequences do reduce the rate
+
+
+def test_plateau_scheduler_property():
+    """Hypothesis: any loss sequence, any factor / patience -- PlateauScheduler tracks torch's ReduceLROnPlateau exactly."""
+    from hypothesis import given, settings, strategies as st
+    from leafgrasp_amd.trainer import PlateauScheduler
+
+    class T:
+        lr = 0.0
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.floats(min_value=1e-3, max_value=10.0, allow_nan=False), min_size=1, max_size=60),
+           st.sampled_from([0.1, 0.5, 0.9]), st.integers(min_value=0, max_value=6), st.sampled_from([1e-6, 1e-4, 1e-3]))
+    def check(seq, factor, patience, min_lr):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=0.0005)
+        ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=factor, patience=patience, min_lr=min_lr)
+        t = T()
+        t.lr = 0.0005
+        mine = PlateauScheduler(t, factor=factor, patience=patience, min_lr=min_lr)
+        for v in seq:
+            ref.step(v)
+            mine.step(v)
+            assert t.lr == opt.param_groups[0]["lr"]
+    check()
+
+
+def test_early_stopping_property():
+    """Hypothesis: the mirror's decisions equal a direct restatement of train_model.py:21-39 on any sequence."""
+    from hypothesis import given, settings, strategies as st
+    from leafgrasp_amd.trainer import EarlyStopping
+
+    class M:
+        def __init__(self):
+            self.v = 0
+
+        def state_dict(self):
+            return {"v": torch.tensor(self.v)}
+
+        def load_state_dict(self, sd):
+            self.v = int(sd["v"])
+
+    @settings(max_examples=80, deadline=None)
+    @given(st.lists(st.floats(min_value=0.0, max_value=2.0, allow_nan=False), min_size=1, max_size=50),
+           st.integers(min_value=1, max_value=8), st.sampled_from([0.0, 0.001, 0.05]))
+    def check(seq, patience, min_delta):
+        es, m = EarlyStopping(patience=patience, min_delta=min_delta), M()
+        best, best_epoch, counter, stop = None, None, 0, None
+        for epoch, v in enumerate(seq):
+            m.v = epoch
+            got = es.step(v, epoch, m)
+            if best is None:
+                best, best_epoch, want = v, epoch, False
+            elif v > best - min_delta:
+                counter += 1
+                want = counter >= patience
+            else:
+                best, best_epoch, counter, want = v, epoch, 0, False
+            assert got == want
+            if got:
+                stop = epoch
+                break
+        assert es.best_epoch == best_epoch and es.best_loss == best
+        if stop is not None:
+            assert m.v == best_epoch      # the best epoch's weights are back
+    check()
