@@ -481,6 +481,8 @@ struct LgLeafWs {   // every array holds capB frames back to back
     unsigned long long* rowbest;  // H
     size_t g_cap, rb_cap;
     int capB;
+    hipStream_t side;          // the clutter-extrema chain runs beside the statistics / median chain
+    hipEvent_t ev_in, ev_side;
 };
 
 void lg_leaf_free(LgLeafWs*& w) {
@@ -488,6 +490,9 @@ void lg_leaf_free(LgLeafWs*& w) {
     void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g, w->rowbest};
     for (void* p : ps)
         if (p) hipFree(p);
+    if (w->side) hipStreamDestroy(w->side);
+    if (w->ev_in) hipEventDestroy(w->ev_in);
+    if (w->ev_side) hipEventDestroy(w->ev_side);
     delete w;
     w = nullptr;
 }
@@ -504,6 +509,9 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
             hipMalloc((void**)&w->hist, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->succ, nb * 4 * LGL_MAXL) ||
             hipMalloc((void**)&w->best, nb * 8))
             return LG_ERR_NOMEM;
+        if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) || hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) ||
+            hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming))
+            return LG_ERR_HIP;
         w->capB = B;
     }
     size_t need = (size_t)w->capB * H * W;
@@ -545,17 +553,22 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     hipMemsetAsync(w->first_leaf, 0xFF, nb * 8, s);
     hipMemsetAsync(w->hist, 0, nb * 4 * LGL_MAXL * 256, s);
     hipMemsetAsync(w->succ, 0xFF, nb * 4 * LGL_MAXL, s);
+    // clutter extrema: independent of the statistics, and like the median chain bound by latency (dependent LDS round trips
+    // there, LDS atomics here) rather than by bandwidth -- the two chains run side by side on two streams
+    hipStream_t s2 = w->side;
+    hipEventRecord(w->ev_in, s);            // the caller's inputs are ready on s
+    hipStreamWaitEvent(s2, w->ev_in, 0);
+    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s2, labels, H, W, w->g);
+    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
+    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
+    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
+    else hipLaunchKernelGGL(k_rowedt<4096>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
+    hipLaunchKernelGGL(k_rowbest, dim3(B), dim3(256), 0, s2, w->rowbest, H, w->best);
+    hipEventRecord(w->ev_side, s2);
     hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, s, labels, n, w->pres);
     hipLaunchKernelGGL(k_prefix, dim3(B), dim3(64), 0, s, w->pres, w->pre, w->nlab);
     hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc,
                        w->first_leaf);
-    // clutter extrema (independent of the statistics)
-    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s, labels, H, W, w->g);
-    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
-    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
-    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
-    else hipLaunchKernelGGL(k_rowedt<4096>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
-    hipLaunchKernelGGL(k_rowbest, dim3(B), dim3(256), 0, s, w->rowbest, H, w->best);
     // exact medians: ranks from the areas, 4 radix passes, successor for even counts
     hipLaunchKernelGGL(k_seed, dim3(B), dim3(LGL_MAXL), 0, s, w->acc, w->st);
     for (int pass = 3; pass >= 0; pass--) {
@@ -563,6 +576,7 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
         hipLaunchKernelGGL(k_select, dim3(1, B), dim3(LGL_MAXL), 0, s, w->st, w->hist, pass, LGL_MAXL);
     }
     hipLaunchKernelGGL(k_successor, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, w->succ);
+    hipStreamWaitEvent(s, w->ev_side, 0);   // join: `best` is read back below
 
     std::vector<int> nlab(nb);
     std::vector<LeafAcc> acc(nb * LGL_MAXL);
