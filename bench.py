@@ -324,6 +324,11 @@ def main():
                                                 "selection incl. CNN, int16 labels + depth resident in HBM"}
             except Exception as e:  # noqa: BLE001
                 out["node_sequence"] = {"error": str(e)}
+            # release the harness (two more library handles with their streams) before the next leg: how many streams a
+            # process holds decides how ROCm maps them to its few hardware queues
+            hz = lab = dep = csvs = None
+            import gc
+            gc.collect()
         if world == 1 and args.train_steps > 0 and not args.no_cnn:
             # secondary figure (never `value`): SURVEY 8f row 4, the inner loop body of scripts/train_model.py:247-265
             try:

@@ -697,7 +697,7 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     ProfScope ps(h, "leaf", s);
-    int rc = lg_leaf_run(h->leaf, labels, depth, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, s, &err);
+    int rc = lg_leaf_run(h->leaf, labels, depth, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, s, h->s_dt[0], &err);
     if (rc) return fail(h, rc, err.c_str());
     return LG_OK;
 }
@@ -712,7 +712,8 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     ProfScope ps(h, "leaf", s);
-    int rc = lg_leaf_run_batch(h->leaf, labels, depth, B, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, status, s, &err);
+    int rc = lg_leaf_run_batch(h->leaf, labels, depth, B, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, status, s,
+                               h->s_dt[0], &err);
     if (rc) return fail(h, rc, err.c_str());
     return LG_OK;
 }

@@ -481,8 +481,7 @@ struct LgLeafWs {   // every array holds capB frames back to back
     unsigned long long* rowbest;  // H
     size_t g_cap, rb_cap;
     int capB;
-    hipStream_t side;          // the clutter-extrema chain runs beside the statistics / median chain
-    hipEvent_t ev_in, ev_side;
+    hipEvent_t ev_in, ev_side; // fences of the side chain (the side stream belongs to the handle)
 };
 
 void lg_leaf_free(LgLeafWs*& w) {
@@ -490,7 +489,6 @@ void lg_leaf_free(LgLeafWs*& w) {
     void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g, w->rowbest};
     for (void* p : ps)
         if (p) hipFree(p);
-    if (w->side) hipStreamDestroy(w->side);
     if (w->ev_in) hipEventDestroy(w->ev_in);
     if (w->ev_side) hipEventDestroy(w->ev_side);
     delete w;
@@ -509,8 +507,7 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
             hipMalloc((void**)&w->hist, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->succ, nb * 4 * LGL_MAXL) ||
             hipMalloc((void**)&w->best, nb * 8))
             return LG_ERR_NOMEM;
-        if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) || hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) ||
-            hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming))
+        if (hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) || hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming))
             return LG_ERR_HIP;
         w->capB = B;
     }
@@ -537,7 +534,7 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
 // host round trip between the passes (the median ranks are seeded on the device), one copy-back at the end.
 int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
                       float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
-                      hipStream_t s, std::string* err) {
+                      hipStream_t s, hipStream_t side, std::string* err) {
     int rc = leaf_ws(w, B, H, W);
     if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
     if (W > 4096) { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
@@ -555,7 +552,9 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     hipMemsetAsync(w->succ, 0xFF, nb * 4 * LGL_MAXL, s);
     // clutter extrema: independent of the statistics, and like the median chain bound by latency (dependent LDS round trips
     // there, LDS atomics here) rather than by bandwidth -- the two chains run side by side on two streams
-    hipStream_t s2 = w->side;
+    // (side = one of the handle's own streams: a stream more per process changes how ROCm maps streams to its few hardware
+    //  queues -- an extra stream here made an unrelated trainer in the same process 2.5x slower)
+    hipStream_t s2 = side ? side : s;
     hipEventRecord(w->ev_in, s);            // the caller's inputs are ready on s
     hipStreamWaitEvent(s2, w->ev_in, 0);
     hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s2, labels, H, W, w->g);
@@ -649,6 +648,7 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
 }
 
 int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
-                lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, std::string* err) {
-    return lg_leaf_run_batch(w, labels, depth, 1, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, nullptr, s, err);
+                lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, hipStream_t side,
+                std::string* err) {
+    return lg_leaf_run_batch(w, labels, depth, 1, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, nullptr, s, side, err);
 }
