@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <stdlib.h>
@@ -916,6 +917,7 @@ struct lg_trainer {
     hipStream_t stream = nullptr, stream_w = nullptr;   // main chain; backward-weights branch
     hipEvent_t ev_dx[8] = {}, ev_wg[8] = {};
     uint64_t* seed_dev = nullptr;
+    bool side_stream = false;                    // backward-weights on stream_w (LG_TRAIN_STREAMS=2); default: in line
     int conv_small_below = 256, conv_split_below = 256;   // convolution shape thresholds (launch_conv)
     bool use_graph = false;                      // LG_TRAIN_GRAPH=1: replay the step as a captured graph (measured: no gain)
     std::map<uint64_t, hipGraphExec_t> graphs;   // key: N, masks drawn on the device, optimizer applied
@@ -1146,6 +1148,12 @@ int lg_train_create(int device, int n_blocks, const int32_t* filters, int attent
     hipMemset(tr->P_, 0, po * 4); hipMemset(tr->G, 0, po * 4); hipMemset(tr->M, 0, po * 4); hipMemset(tr->V, 0, po * 4);
     hipMemset(tr->B, 0, bo * 4); hipMemset(tr->state, 0, 16); hipMemset(tr->loss, 0, 16);
     hipDeviceSynchronize();
+    // Backward-weights runs in line on the one stream by default.  On a second stream (LG_TRAIN_STREAMS=2: stream_w, dX double
+    // buffered, event fences) it overlaps the BatchNorm-backward / backward-data chain and gains 2-5 % at batches 64..1024 --
+    // but each of the ~12 stream hops of a step costs ~15 us (0.65 vs 0.67 ms at batch 16), and how ROCm maps a process's
+    // streams to its few hardware queues depends on how many streams exist when these two are created: for 2 of 9 probed
+    // counts (tests/tools/streams_probe.py) the two-stream step was 2.2-2.5x slower.
+    if (const char* e = getenv("LG_TRAIN_STREAMS")) tr->side_stream = atoi(e) == 2;
     *out = tr;
     return LG_OK;
 }
@@ -1337,7 +1345,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
     // encoder.  Main chain per layer: BN backward (reduce, dx) -> backward-data convolution; the backward-weights
     // convolution of the layer (+ the ordered sum of its pixel slices) runs beside it on the second stream.  dX is double
     // buffered: layer li's dX is rewritten by layer li-2, which first waits for layer li's backward-weights.
-    hipStream_t sw = tr->stream_w;
+    hipStream_t sw = tr->side_stream ? tr->stream_w : s;
     int cur = 0;
     const int nl = (int)tr->layers.size();
     for (int li = nl - 1; li >= 0; li--) {
@@ -1346,7 +1354,7 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
         const float* dm = L.pool ? tr->masks + (size_t)N * L.mask : nullptr;
         const float *mu = tr->mean + L.st, *rs = tr->rstd + L.st, *g = tr->P_ + L.g, *be = tr->P_ + L.be;
         float* dXl = tr->dX[li & 1];
-        if (li + 2 < nl) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li + 2], 0));
+        if (tr->side_stream && li + 2 < nl) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li + 2], 0));
         const int S = bn_chunks(N, L.co, L.wi * L.wi), chunk = (N + S - 1) / S, Sy = (N + chunk - 1) / chunk;
         if (L.pool) {
             hipLaunchKernelGGL(lgt_bn_bwd_reduce_kernel<true>, dim3(L.co, Sy), dim3(256), 0, s, L.x, tr->dA[cur], mu, rs, g, be, dm,
@@ -1368,19 +1376,22 @@ static int enqueue_step(lg_trainer* tr, int N, bool draw_masks, int apply_update
                                    dm, tr->G + L.g, tr->G + L.be, dXl, N, L.co, L.wi);
             }
         }
-        TR_HIP(hipEventRecord(tr->ev_dx[li], s));
-        TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));
+        if (tr->side_stream) {
+            TR_HIP(hipEventRecord(tr->ev_dx[li], s));
+            TR_HIP(hipStreamWaitEvent(sw, tr->ev_dx[li], 0));
+        }
         const size_t nw = (size_t)9 * L.ci * L.co;
         const int ntiles = conv_tiles(L.wi, N, kWgTile), Sw = wgrad_split(ntiles, nw, (int)(cdiv(L.co, 64) * cdiv(L.ci, 32)));
         launch_wgrad(L.wi, dim3(Sw, cdiv(L.co, 64), cdiv(L.ci, 32)), sw, ain, dXl, tr->partial, N, L.ci, L.co, ntiles);
         hipLaunchKernelGGL(lgt_wreduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, sw, tr->partial, Sw, L.ci, L.co, tr->G + L.w);
-        TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
+        if (tr->side_stream) TR_HIP(hipEventRecord(tr->ev_wg[li], sw));
         if (li > 0) {   // backward-data: a convolution of dX with the mirrored, channel-swapped weights
             launch_conv(tr, L.wi, s, dXl, L.wpd, (const float*)nullptr, tr->dA[cur ^ 1], N, L.co, L.ci);
             cur ^= 1;
         }
     }
-    for (int li = 0; li < std::min(2, nl); li++) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li], 0));   // sw is in order: 0 covers all
+    if (tr->side_stream)
+        for (int li = 0; li < std::min(2, nl); li++) TR_HIP(hipStreamWaitEvent(s, tr->ev_wg[li], 0));   // sw is in order
     // ---------------- optimizer
     hipLaunchKernelGGL(lgt_sumsq_kernel, dim3(kNormParts), dim3(256), 0, s, tr->G, tr->n_params, tr->norm_part);
     hipLaunchKernelGGL(lgt_norm_kernel, dim3(1), dim3(64), 0, s, tr->norm_part, kNormParts, apply_update ? 1 : 0, tr->state);
