@@ -149,6 +149,10 @@ def main():
     import threading
 
     params = SI.cnn_closed_form_params(seed=0)
+    _idle = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("LG_BENCH_IDLE_STREAMS", "0")))]   # diagnostic:
+    for _st in _idle:                          # streams alive before the selector decide the stream-to-queue mapping
+        with torch.cuda.stream(_st):
+            torch.zeros(1, device=dev)
     sels = []
     for _ in range(max(1, args.inflight)):
         sel = L.GraspPointSelector(dev, load_model=False)
