@@ -1,3 +1,8 @@
+"""How the training step's time depends on the number of other streams alive in the process when the trainer is created
+(ROCm maps streams to a few hardware queues in creation order).  With LG_TRAIN_STREAMS=2 (backward-weights on a second
+stream) 2 of 9 counts gave a 2.2-2.5x slower step; the default one-stream step is flat (0.611-0.616 ms at batch 16).
+    python tests/tools/streams_probe.py            # default build: one stream
+    LG_TRAIN_STREAMS=2 python tests/tools/streams_probe.py"""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
