@@ -10,6 +10,8 @@
 #include <functional>
 #include <string>
 #include <atomic>
+#include <memory>
+#include <sched.h>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -18,75 +20,9 @@
 #include "lg_cnn.h"
 #include "lg_leaf.h"
 #include "lg_internal.h"
+#include "lg_pool.h"
 
 #define LG_VERSION_STR "leafgrasp-gfx950 0.1"
-
-// Persistent host worker pool (orientation + result post-processing): spawning 16 threads per call costs
-// more than the work itself at B = 128.
-class LgPool {
-public:
-    explicit LgPool(int n) {
-        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
-    }
-    ~LgPool() {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    int size() const { return (int)th_.size(); }
-    void run(int n, const std::function<void(int)>& fn) {  // calls fn(0..n-1), returns when all are done
-        if (n <= 0) return;
-        if (n == 1 || th_.empty()) {
-            for (int i = 0; i < n; i++) fn(i);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn; n_ = n; next_.store(0); done_.store(0); gen_++;
-        }
-        cv_.notify_all();
-        work();  // the caller helps
-        std::unique_lock<std::mutex> l(m_);
-        cv_done_.wait(l, [this] { return done_.load() >= n_; });
-        fn_ = nullptr;
-    }
-
-private:
-    void work() {
-        for (;;) {
-            int i = next_.fetch_add(1);
-            if (i >= n_) break;
-            (*fn_)(i);
-            if (done_.fetch_add(1) + 1 >= n_) {
-                std::lock_guard<std::mutex> l(m_);
-                cv_done_.notify_all();
-            }
-        }
-    }
-    void loop() {
-        unsigned long long seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-            }
-            if (fn_) work();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, cv_done_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0;
-    std::atomic<int> next_{0}, done_{0};
-    unsigned long long gen_ = 0;
-    bool stop_ = false;
-};
 
 struct LgProfSlot {
     std::string name;
@@ -129,6 +65,11 @@ struct lg_ctx {
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
     LgPool* pool = nullptr;
+    // experiment switches, read ONCE at lg_create (never on the per-call path)
+    int opt_subbatch = 0;        // LG_SUBBATCH=n: sub-batch multi-stream pipeline inside lg_select_grasp (0 = off)
+    bool opt_trace = false;      // LG_TRACE: per-call timeline on stderr
+    bool opt_no_skip = false;    // LG_NO_SKIP: lg_final_kernel without the constant-tile fast path (dense-path roofline)
+    bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
 };
 
 namespace {
@@ -237,10 +178,13 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     // LG_EXPORT_MEMCPY=1 (A/B) or an unmapped allocation: whole-batch hipMemcpyAsync instead.
     if (getenv("LG_EXPORT_MEMCPY") || hipHostGetDevicePointer((void**)&h->bits_host_dev, h->bits_host, 0) != hipSuccess)
         h->bits_host_dev = nullptr;   // fall back to a full-batch hipMemcpyAsync
+    LG_HIP(h, dev_alloc(&h->ws_valid, px));   // validity plane for callers that do not want it back
     LG_HIP(h, dev_alloc(&h->cand_xy, (size_t)nB * nK * 2));
     LG_HIP(h, dev_alloc(&h->cand_n, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->cand_info, (size_t)nB * nK * 2));
-    LG_HIP(h, dev_alloc(&h->patches, (size_t)nB * nK * 9 * 1024));
+    // candidate patches as haloed planes (the CNN's staging layout); the halo is zeroed here, once
+    LG_HIP(h, dev_alloc(&h->patches, (size_t)nB * nK * lg_cnn_halo_patch_floats()));
+    LG_HIP(h, hipMemset(h->patches, 0, (size_t)nB * nK * lg_cnn_halo_patch_floats() * sizeof(float)));
     LG_HIP(h, dev_alloc(&h->logits, (size_t)nB * nK));
     LG_HIP(h, hipHostMalloc((void**)&h->h_xy, sizeof(int32_t) * nB * nK * 2));
     LG_HIP(h, hipHostMalloc((void**)&h->h_n, sizeof(int32_t) * nB));
@@ -337,9 +281,22 @@ int lg_create(int device, lg_handle* out) {
         delete h;
         return LG_ERR_HIP;
     }
+    // host workers: this process's share of the CPUs it may run on (one process per GPU: LOCAL_WORLD_SIZE ranks split the
+    // node), at most 16
     unsigned hw = std::thread::hardware_concurrency();
-    h->host_threads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) hw = (unsigned)CPU_COUNT(&set);
+    }
+    unsigned ranks = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = (unsigned)std::max(1, atoi(e));
+    h->host_threads = (int)std::max(1u, std::min((hw ? hw : 1u) / ranks, 16u));
     if (const char* e = getenv("LG_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
+    if (const char* e = getenv("LG_SUBBATCH")) h->opt_subbatch = std::max(1, atoi(e));
+    h->opt_trace = getenv("LG_TRACE") != nullptr;
+    h->opt_no_skip = getenv("LG_NO_SKIP") != nullptr;
+    h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
@@ -529,8 +486,8 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     gaussian1d(a.k1);
-    a.no_skip = getenv("LG_NO_SKIP") ? 1 : 0;
-    a.nt_stores = getenv("LG_NT_STORES") ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
+    a.no_skip = h->opt_no_skip ? 1 : 0;
+    a.nt_stores = h->opt_nt_stores ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
         ProfScope ps(h, "final", s, true);
         lg_launch_final(a, s, ps.slot ? ps.e0 : nullptr, ps.slot ? ps.e1 : nullptr);
@@ -545,6 +502,8 @@ int make_plan(lg_ctx* h, Plan& pl, const float* depth, const uint8_t* mask, int 
     if (pin) pl.P = *pin; else lg_default_params(&pl.P);
     if (pl.P.stem_se < 1 || pl.P.stem_se > 64 || pl.P.stem_bottom_div < 1)
         return fail(h, LG_ERR_INVALID, "stem_se must be in [1,64], stem_bottom_div >= 1");
+    if (pl.P.nms_min_distance < 0 || pl.P.pregrasp_clearance < 0 || pl.P.pregrasp_clearance > 31)
+        return fail(h, LG_ERR_INVALID, "nms_min_distance must be >= 0, pregrasp_clearance in [0,31]");
     pl.B = B; pl.H = H; pl.W = W; pl.WW = (W + 63) / 64;
     pl.tiles_x = (W + LG_TW - 1) / LG_TW; pl.tiles_y = (H + LG_TH - 1) / LG_TH;
     if (pl.tiles_x * pl.tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "image too large for the top-k tile table");
@@ -617,7 +576,7 @@ int lg_gather_patches(lg_handle h, const float* depth, const uint8_t* mask, cons
     hipStream_t s = (hipStream_t)stream_;
     LG_HIP(h, hipSetDevice(h->device));
     ProfScope ps(h, "gather", s);
-    lg_launch_gather(depth, mask, maps, B, H, W, k, xy, n, patches, s);
+    lg_launch_gather(depth, mask, maps, B, H, W, k, xy, n, patches, false, s);
     LG_HIP(h, hipGetLastError());
     return LG_OK;
 }
@@ -743,7 +702,7 @@ int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     ProfScope ps(h, "cnn", s);
-    int rc = lg_cnn_run(&h->cnn, patches, N, logits, s, &err);
+    int rc = lg_cnn_run(&h->cnn, patches, false, N, logits, s, &err);
     if (rc) return fail(h, rc, err.c_str());
     LG_HIP(h, hipGetLastError());
     return LG_OK;
@@ -770,10 +729,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
             if (rc) return rc;
             pl.maps[i] = h->ws_maps[i];
         }
-    if (!pl.valid) {
-        if (!h->ws_valid) LG_HIP(h, hipMalloc((void**)&h->ws_valid, (size_t)h->capB * h->capH * h->capW));
-        pl.valid = h->ws_valid;
-    }
+    if (!pl.valid) pl.valid = h->ws_valid;
     const int K = P.top_k;
     const size_t px = (size_t)H * W;
     const int tiles = pl.tiles_x * pl.tiles_y;
@@ -787,8 +743,8 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     int SB = B;
     // Measured on MI355X (B=128, 1080p): SB=32 is 14.8 ms/step vs 11.5 ms unpiped -- the chain
     // D(0)->F(0)->T(0) must drain before the first CNN launch, and D's latency does not shrink with SB.
-    // Kept for experiments (LG_SUBBATCH=n); the default is one sub-batch.
-    if (const char* e = getenv("LG_SUBBATCH")) SB = std::max(1, atoi(e));
+    // Kept for experiments (LG_SUBBATCH=n in the environment when the handle is created); the default is one sub-batch.
+    if (h->opt_subbatch > 0) SB = h->opt_subbatch;
     const int nsub = (B + SB - 1) / SB;
     const bool piped = nsub > 1;
     hipStream_t sD[2] = {piped ? h->s_dt[0] : s, piped ? h->s_dt[1] : s};
@@ -812,16 +768,16 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                 const float* mp[LG_NUM_MAPS];
                 for (int i = 0; i < LG_NUM_MAPS; i++) mp[i] = pl.maps[i] ? pl.maps[i] + off * px : nullptr;
                 lg_launch_gather(depth + off * px, mask + off * px, mp, n, H, W, K, h->cand_xy + (size_t)off * K * 2,
-                                 h->cand_n + off, h->patches + (size_t)off * K * 9 * 1024, sM);
+                                 h->cand_n + off, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, sM);
             }
             std::string err;
             ProfScope ps(h, "cnn", sM);
-            int r2 = lg_cnn_run(&h->cnn, h->patches + (size_t)off * K * 9 * 1024, n * K, h->logits + (size_t)off * K, sM, &err);
+            int r2 = lg_cnn_run(&h->cnn, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, n * K, h->logits + (size_t)off * K, sM, &err);
             if (r2) return fail(h, r2, err.c_str());
         }
         return LG_OK;
     };
-    const bool trace = getenv("LG_TRACE") != nullptr;
+    const bool trace = h->opt_trace;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     hipEvent_t tev[6] = {nullptr};

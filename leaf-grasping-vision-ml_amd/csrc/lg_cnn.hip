@@ -1,11 +1,18 @@
 // GraspPointCNN forward on gfx950 (see lg_cnn.h).  Reference: scripts/utils/ml_grasp_optimizer/model.py:5-128.
 //
-// Conv layers: out[n][co][y][x] = relu(b[co] + sum_{ky,kx,ci} w[ky][kx][ci][co] * in[n][ci][y+ky-1][x+kx-1])
-// as D = W * X on v_mfma_f32_32x32x2_f32 with M = 32 output channels, N = 32 consecutive pixels of the
-// planar image, K = (tap, input channel) pairs.  A operand (weights) and B operand (im2col of an LDS
-// staged input tile) are one VGPR each; lanes 0..31 carry k, lanes 32..63 carry k+1.
-// Accumulator lane l holds pixel l&31 and channels (r&3)+8(r>>2)+4(l>>5): a store instruction writes 32
-// consecutive pixels of one channel row = one 128-byte line.
+// Activation layout between the layers ("haloed planes"): a WI x WI feature map is stored as (WI + 2) rows of
+// WI + 4 floats -- pixel (y, x) at [y + 1][x + 1], a zero row above and below, a zero column left, three right -- so
+// that (1) the zero padding of every 3x3 convolution is DATA, not address logic, and (2) the rows a workgroup stages
+// (a band of the image incl. its halo, for a chunk of channels) are contiguous 16-byte-aligned runs of global memory:
+// every staging transfer is a `global_load_lds_dwordx4` (1 KiB per wave instruction).  Measured on MI355X
+// (tools/ubench/mfma_issue.hip, profiles/r02_ubench_mfma_f32_issue_costs.txt): the vector-memory path moves 64 B/clk/CU
+// with 16-byte lanes and 8 B/clk/CU with 4-byte lanes, whatever else the CU does -- the 4-byte staging of the first
+// version of these kernels kept that path busy for 44 % of a chunk's time.  The halos are written once (buffers are
+// zeroed at allocation, one buffer per layer) and never touched again: epilogues store interior pixels only.
+//
+// Conv layers: out[n][co][y][x] = relu(b[co] + sum_{ky,kx,ci} w[ky][kx][ci][co] * in[n][ci][y+ky-1][x+kx-1]).
+// f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) shares the SIMD's FMA lanes with the VALU: every other vector
+// instruction of a wave ADDS its 4 cycles to the MFMA time (same profile file), LDS reads do not.
 #include "lg_cnn.h"
 
 #include <math.h>
@@ -17,12 +24,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef LG_WS_EXP
-#define LG_WS_EXP 0   // timing ablations of lg_wino_ws_kernel (wrong results!): 1 no A loads, 2 no B reads, 4 no transform, 8 no input
-#endif
-
-__device__ float lg_zero_pad[4];  // zero-initialised source for padded / out-of-range direct-to-LDS lanes
-
 namespace {
 
 struct LayerCfg { int cin, cinp, cout, wi; bool pool; };
@@ -30,34 +31,60 @@ constexpr LayerCfg kLayers[6] = {
     {9, 10, 64, 32, false}, {64, 64, 64, 32, true},   {64, 64, 128, 16, false},
     {128, 128, 128, 16, true}, {128, 128, 256, 8, false}, {256, 256, 256, 8, true}};
 
-// WG = 256 threads = 4 waves; wave tile = 2 pixel-blocks x 2 channel-blocks (4 accumulators).
-// PP = pixel-block pairs per workgroup, CP = channel-block pairs per workgroup, PP*CP == 4.
-template <int CIN, int CINP, int COUT, int WI, bool POOL, int KC, int PP, int CP>
+constexpr int lg_wp(int wi) { return wi + 4; }                   // row pitch of a haloed plane
+constexpr int lg_plane(int wi) { return (wi + 2) * (wi + 4); }   // floats per haloed plane
+
+#define LG_DMA16(src, dst)                                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                  \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define LG_DMA4(src, dst)                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                  \
+                                     (__attribute__((address_space(3))) void*)(dst), 4, 0, 0)
+
+// [N][9][32][32] (the C-ABI's patch layout) -> haloed [N][9][34][36]; the halo is never written
+__global__ __launch_bounds__(256) void lg_repack_kernel(const float* __restrict__ in, float* __restrict__ out, long long nplanes) {
+    const long long pl = blockIdx.x;
+    if (pl >= nplanes) return;
+    const float4* src = reinterpret_cast<const float4*>(in + pl * 1024);
+    float* dst = out + pl * lg_plane(32);
+    const int t = threadIdx.x, y = t >> 3, x4 = (t & 7) * 4;
+    const float4 v = src[t];
+    float* d = dst + (y + 1) * lg_wp(32) + x4 + 1;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Direct implicit GEMM, D = W * X on v_mfma_f32_32x32x2_f32: M = 32 output channels, N = 32 consecutive pixels,
+// K = (tap, input channel) pairs; A (weights) and B (im2col of an LDS staged tile) one VGPR each, lanes 0..31 carry k,
+// lanes 32..63 k+1.  The reference path of the tests (LG_CNN_DIRECT=1 / LG_CNN_WINO_MASK) -- not on the default path.
+// WG = 256 threads = 4 waves; wave tile = 2 pixel-blocks x 2 channel-blocks; PP x CP wave arrangement.
+template <int CIN, int CINP, int COUT, int WI, bool POOL, bool OUT_HALO, int KC, int PP, int CP>
 __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wp,
-                                                         const float* __restrict__ bias, float* __restrict__ out) {
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         const float* __restrict__ zeros) {
     static_assert(PP * CP == 4, "4 waves per workgroup");
     constexpr int PBROWS = 32 / WI > 0 ? 32 / WI : 1;   // image rows per 32-pixel block (WI=32:1, 16:2, 8:4)
     constexpr int ROWS = 2 * PP * PBROWS;               // output rows per workgroup
     constexpr int TR = ROWS + 2;                        // staged input rows (halo 1)
     constexpr int TWID = WI + 2;
-    constexpr int COUT_T = 64 * CP;                     // output channels per workgroup
-    constexpr int IN_CH_STRIDE = TR * TWID;             // linear: the LDS image is filled by global_load_lds
+    constexpr int COUT_T = 64 * CP;
+    constexpr int IN_CH_STRIDE = TR * TWID;
     constexpr int IN_ELEMS = KC * TR * TWID;
     constexpr int NIN = (IN_ELEMS + 255) / 256;
-    constexpr int IN_PAD = NIN * 256;                   // every lane of every load instruction has a slot
+    constexpr int IN_PAD = NIN * 256;
     constexpr int W4_ELEMS = 9 * KC * (COUT_T / 4);
     constexpr int NW4 = (W4_ELEMS + 255) / 256;
-    constexpr int BUF = IN_PAD + NW4 * 256 * 4;         // floats per stage
-    // ONE shared object (a second one makes hipcc drain vmcnt before every ds_read): [stage][input | weights]
+    constexpr int BUF = IN_PAD + NW4 * 256 * 4;
+    constexpr int PLANE = lg_plane(WI), WP = lg_wp(WI);
     __shared__ __attribute__((aligned(16))) float s_buf[2 * BUF];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wp_i = wave % PP, wc_i = wave / PP;       // pixel-pair / channel-pair of this wave
+    const int wp_i = wave % PP, wc_i = wave / PP;
     constexpr int BANDS = WI / ROWS > 0 ? WI / ROWS : 1;
     const int n = blockIdx.x / (BANDS * (COUT / COUT_T));
     const int rem = blockIdx.x % (BANDS * (COUT / COUT_T));
     const int band = rem % BANDS, ct = rem / BANDS;
-    const int y0 = band * ROWS;                          // first output row of the workgroup
+    const int y0 = band * ROWS;
     const int co0 = ct * COUT_T;
 
     f32x16 acc[2][2];
@@ -68,38 +95,28 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    // per-lane B-operand base offsets (within one channel plane of s_in) for the two pixel blocks
     const int p = lane & 31, kh = lane >> 5;
     int boff[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const int pb = wp_i * 2 + i;                      // pixel block inside the workgroup tile
-        const int row = pb * PBROWS + p / WI, x = p % WI; // output pixel inside the tile
-        boff[i] = row * TWID + x;                         // + ky*TWID + kx addresses the tap
+        const int pb = wp_i * 2 + i;
+        const int row = pb * PBROWS + p / WI, x = p % WI;
+        boff[i] = row * TWID + x;
     }
-    const int aoff = (wc_i * 64) + (lane & 31);           // A-operand: channel inside the tile (+32 for block 1)
+    const int aoff = (wc_i * 64) + (lane & 31);
 
-    const float* in_n = in + (size_t)n * CIN * WI * WI;
-    // Direct-to-LDS staging (global_load_lds): chunk c+1 streams into the other LDS stage while the MFMA loop
-    // works on chunk c; no staging registers, no LDS write pass, one barrier per chunk.  The LDS destination of
-    // one wave instruction is wave-uniform base + lane * size, so both images are stored in load order; zero
-    // padding of the conv (and the slots past the end) is fetched from a zeroed device word.
-    // Source offsets are chunk-invariant apart from the channel base: computed once, so issuing a chunk costs a
-    // few VALU instructions per load instead of ~25 (the two workgroups of a CU run in lock-step; address math
-    // at every chunk boundary would leave the MFMA pipe idle on both).
-    int off_in[NIN];   // offset inside the chunk's first channel plane group, or -1: zero padding / unused slot
+    const float* in_n = in + (size_t)n * CIN * PLANE;
+    int off_in[NIN];   // offset inside the chunk's first haloed plane group, or -1: unused slot / padded channel
     int ci_in[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
         const int idx = t + 256 * j;
         const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
         const int ry = r2 / TWID, rx = r2 % TWID;
-        const int gy = y0 - 1 + ry, gx = rx - 1;
-        const bool ok = idx < IN_ELEMS && gy >= 0 && gy < WI && gx >= 0 && gx < WI;
-        off_in[j] = ok ? (ci * WI + gy) * WI + gx : -1;
+        off_in[j] = idx < IN_ELEMS ? ci * PLANE + (y0 + ry) * WP + rx : -1;   // haloed row y0 + ry = image row y0 - 1 + ry
         ci_in[j] = ci;
     }
-    int off_w[NW4];    // offset into the packed weights for c0 = 0, or -1
+    int off_w[NW4];
 #pragma unroll
     for (int j = 0; j < NW4; j++) {
         const int idx = t + 256 * j;
@@ -109,27 +126,24 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
     }
     auto issue_chunk = [&](int c0, int stage) {
         float* sb = s_buf + stage * BUF;
-        const float* in_c = in_n + (size_t)c0 * WI * WI;
+        const float* in_c = in_n + (size_t)c0 * PLANE;
         const float* w_c = wp + (size_t)c0 * COUT;
 #pragma unroll
         for (int j = 0; j < NIN; j++) {
             const bool ok = off_in[j] >= 0 && (CIN == CINP || c0 + ci_in[j] < CIN);
-            const float* src = ok ? in_c + off_in[j] : lg_zero_pad;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
+            const float* src = ok ? in_c + off_in[j] : zeros;
+            LG_DMA4(src, sb + 256 * j + 64 * wave);
         }
 #pragma unroll
         for (int j = 0; j < NW4; j++) {
-            const float* src = off_w[j] >= 0 ? w_c + off_w[j] : lg_zero_pad;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + IN_PAD + 4 * (256 * j + 64 * wave)),
-                                             16, 0, 0);
+            const float* src = off_w[j] >= 0 ? w_c + off_w[j] : zeros;
+            LG_DMA16(src, sb + IN_PAD + 4 * (256 * j + 64 * wave));
         }
     };
     issue_chunk(0, 0);
     int stage = 0;
     for (int c0 = 0; c0 < CINP; c0 += KC, stage ^= 1) {
-        __syncthreads();   // own loads landed (vmcnt(0)) + every wave is done with the other stage
+        __syncthreads();
         if (c0 + KC < CINP) issue_chunk(c0 + KC, stage ^ 1);
         const float* s_in = s_buf + stage * BUF;
         const float* s_w = s_in + IN_PAD;
@@ -151,9 +165,12 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
         }
     }
 
-    // ---- epilogue: bias + ReLU (+ 2x2 max pool), planar NCHW store
+    // ---- epilogue: bias + ReLU (+ 2x2 max pool); interior of the haloed plane (or a dense plane for the head)
     constexpr int WO = POOL ? WI / 2 : WI;
-    float* out_n = out + (size_t)n * COUT * WO * WO;
+    constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;                 // output row pitch
+    constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;        // output plane
+    constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;              // offset of pixel (0, 0)
+    float* out_n = out + (size_t)n * COUT * OPL + OO;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -164,26 +181,25 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const int pb = wp_i * 2 + i;
-                    const int pix = (y0 * WI) + pb * 32 + p;   // linear pixel index in the image plane
-                    out_n[(size_t)co * WI * WI + pix] = fmaxf(acc[i][j][r] + bv, 0.0f);
+                    const int row = y0 + pb * PBROWS + p / WI, x = p % WI;
+                    out_n[(size_t)co * OPL + row * OP + x] = fmaxf(acc[i][j][r] + bv, 0.0f);
                 }
             } else {
                 if (WI == 32) {
-                    // the wave's two pixel blocks are image rows y0+2a, y0+2a+1
-                    float v = fmaxf(acc[0][j][r], acc[1][j][r]);
+                    float v = fmaxf(acc[0][j][r], acc[1][j][r]);   // the wave's two pixel blocks are rows y0+2a, y0+2a+1
                     v = fmaxf(v, __shfl_xor(v, 1, 64));
                     const int yo = (y0 + wp_i * 2) / 2, xo = p >> 1;
-                    if ((p & 1) == 0) out_n[((size_t)co * WO + yo) * WO + xo] = fmaxf(v + bv, 0.0f);
+                    if ((p & 1) == 0) out_n[(size_t)co * OPL + yo * OP + xo] = fmaxf(v + bv, 0.0f);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
                         float v = acc[i][j][r];
-                        v = fmaxf(v, __shfl_xor(v, WI, 64));   // row pair inside the pixel block
+                        v = fmaxf(v, __shfl_xor(v, WI, 64));
                         v = fmaxf(v, __shfl_xor(v, 1, 64));
                         const int pb = wp_i * 2 + i;
                         const int row = y0 + pb * PBROWS + p / WI, x = p % WI;
                         if (((p / WI) & 1) == 0 && (x & 1) == 0)
-                            out_n[((size_t)co * WO + (row >> 1)) * WO + (x >> 1)] = fmaxf(v + bv, 0.0f);
+                            out_n[(size_t)co * OPL + (row >> 1) * OP + (x >> 1)] = fmaxf(v + bv, 0.0f);
                     }
                 }
             }
@@ -192,18 +208,19 @@ __global__ __launch_bounds__(256, 2) void lg_conv3x3_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Layer 0 (9 input channels, 32x32, no pool) as a workgroup per (patch, 64 output channels) that walks the four 8-row
-// bands of its patch: the 23 KB weight image is staged once instead of once per band and the next band's input streams
-// into the other LDS stage while the current one is multiplied -- the generic kernel above, launched per band, spent
-// 0.43 of this layer's time on the staging round trip of a 180-MFMA workgroup (MFMA busy 0.57).
+// Layer 0 (9 input channels, 32x32, no pool): one workgroup per (patch, 64 output channels) walks the four 8-row bands
+// of its patch.  The 23 KB weight image is staged once; the next band's input (10 haloed rows x 36 floats per channel:
+// 90 16-byte pieces, 4 transfers per thread and band instead of 14 four-byte ones) streams into the other LDS stage
+// while the current one is multiplied.  The 10th (padding) channel reads a zeroed plane.
 template <int COUT>
 __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restrict__ in, const float* __restrict__ wp,
-                                                          const float* __restrict__ bias, float* __restrict__ out) {
-    constexpr int CIN = 9, CINP = 10, WI = 32, ROWS = 8, TR = ROWS + 2, TWID = WI + 2, BANDS = WI / ROWS;
-    constexpr int IN_CH_STRIDE = TR * TWID;
-    constexpr int IN_ELEMS = CINP * TR * TWID;
-    constexpr int NIN = (IN_ELEMS + 255) / 256;
-    constexpr int IN_PAD = NIN * 256;
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          const float* __restrict__ zeros) {
+    constexpr int CIN = 9, CINP = 10, WI = 32, ROWS = 8, TR = ROWS + 2, WP = lg_wp(WI), PLANE = lg_plane(WI), BANDS = WI / ROWS;
+    constexpr int IN_CH_STRIDE = TR * WP;                 // 360 floats
+    constexpr int PPC = IN_CH_STRIDE / 4;                 // 16-byte pieces per channel and band
+    constexpr int NIN = (CINP * PPC + 255) / 256;
+    constexpr int IN_PAD = NIN * 256 * 4;                 // floats per input stage
     constexpr int W4_ELEMS = 9 * CINP * (64 / 4);
     constexpr int NW4 = (W4_ELEMS + 255) / 256;
     __shared__ __attribute__((aligned(16))) float s_buf[2 * IN_PAD + NW4 * 256 * 4];   // [input stage 0 | stage 1 | weights]
@@ -213,39 +230,31 @@ __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // pixel-block pair of this wave: band rows 2w, 2w+1
     const int n = blockIdx.x / (COUT / 64), co0 = (blockIdx.x % (COUT / 64)) * 64;
     const int p = lane & 31, kh = lane >> 5;
-    const int boff0 = (2 * wave) * TWID + p, boff1 = (2 * wave + 1) * TWID + p;
+    const int boff0 = (2 * wave) * WP + p, boff1 = (2 * wave + 1) * WP + p;
     const int aoff = lane & 31;
-    const float* in_n = in + (size_t)n * CIN * WI * WI;
+    const float* in_n = in + (size_t)n * CIN * PLANE;
 
-    // staging slots: (channel, row of the band window, column); the row decides validity per band
-    int off0[NIN], ry_[NIN];
+    const float* src0[NIN];   // band 0 source of every staging slot; + ROWS * WP floats per band for real channels
+    bool real[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
-        const int idx = t + 256 * j;
-        const int ci = idx / (TR * TWID), r2 = idx % (TR * TWID);
-        const int ry = r2 / TWID, gx = r2 % TWID - 1;
-        const bool okx = idx < IN_ELEMS && ci < CIN && gx >= 0 && gx < WI;
-        off0[j] = (ci * WI + ry - 1) * WI + gx;           // band 0; + ROWS * WI per band
-        ry_[j] = okx ? ry : -1000;                        // never valid
+        const int e = t + 256 * j;
+        const int ci = e / PPC, piece = e % PPC;
+        real[j] = ci < CIN;
+        src0[j] = real[j] ? in_n + ci * PLANE + 4 * piece : zeros + 4 * piece;   // slots past the image: zeros, into LDS slack
     }
     auto issue_input = [&](int band, int stage) {
         float* sb = s_buf + stage * IN_PAD;
 #pragma unroll
-        for (int j = 0; j < NIN; j++) {
-            const int gy = band * ROWS - 1 + ry_[j];
-            const float* src = (gy >= 0 && gy < WI) ? in_n + off0[j] + band * ROWS * WI : lg_zero_pad;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * wave), 4, 0, 0);
-        }
+        for (int j = 0; j < NIN; j++) LG_DMA16(src0[j] + (real[j] ? band * ROWS * WP : 0), sb + 4 * (256 * j + 64 * wave));
     };
 #pragma unroll
     for (int j = 0; j < NW4; j++) {   // weights once: [tap][ci][64 channels], 16 bytes per lane
         const int idx = t + 256 * j;
         const int q = idx % 16, rest = idx / 16;
         const int ci = rest % CINP, tap = rest / CINP;
-        const float* src = idx < W4_ELEMS ? wp + ((size_t)tap * CINP + ci) * COUT + co0 + 4 * q : lg_zero_pad;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(s_w + 4 * (256 * j + 64 * wave)), 16, 0, 0);
+        const float* src = idx < W4_ELEMS ? wp + ((size_t)tap * CINP + ci) * COUT + co0 + 4 * q : zeros;
+        LG_DMA16(src, s_w + 4 * (256 * j + 64 * wave));
     }
     issue_input(0, 0);
     float bv[2][16];
@@ -274,16 +283,16 @@ __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restric
                 const int ci = k0 + kh;
                 const float a0 = s_w[(tap * CINP + ci) * 64 + aoff];
                 const float a1 = s_w[(tap * CINP + ci) * 64 + aoff + 32];
-                const float b0 = s_in[ci * IN_CH_STRIDE + boff0 + ky * TWID + kx];
-                const float b1 = s_in[ci * IN_CH_STRIDE + boff1 + ky * TWID + kx];
+                const float b0 = s_in[ci * IN_CH_STRIDE + boff0 + ky * WP + kx];
+                const float b1 = s_in[ci * IN_CH_STRIDE + boff1 + ky * WP + kx];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-        // bias + ReLU, one 128-byte row segment per (channel, row) and store instruction
-        float* out_n = out + (size_t)n * COUT * WI * WI;
+        // bias + ReLU into the interior of the haloed output plane: 32 consecutive floats per (channel, row) and store
+        float* out_n = out + (size_t)n * COUT * PLANE + WP + 1;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -292,54 +301,51 @@ __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restric
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const int y = band * ROWS + 2 * wave + i;
-                    out_n[((size_t)co * WI + y) * WI + p] = fmaxf(acc[i][j][r] + bv[j][r], 0.0f);
+                    out_n[(size_t)co * PLANE + y * WP + p] = fmaxf(acc[i][j][r] + bv[j][r], 0.0f);
                 }
             }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Winograd F(2x2,3x3) form of the same 3x3 convolutions (layers 1..5; layer 0 has 9 input channels and stays
-// direct):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input tile d / 2x2 output tile Y, i.e. 16 independent
-// contractions over the input channels instead of 36 multiply-adds per output pair: 2.25x fewer MFMA flops,
-// still exact-f32 products and f32 accumulation (v_mfma_f32_16x16x4_f32).
+// Winograd F(2x2,3x3):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input tile d / 2x2 output tile Y, 16 independent
+// contractions over the input channels: 2.25x fewer MFMA flops than the direct form, still exact-f32 products and f32
+// accumulation (v_mfma_f32_16x16x4_f32).  Used for the encoder shapes F(4x4,3x3) below does not cover, and as its A/B.
 //
-// Workgroup = 256 threads = 32 tiles x 64 output channels x all 16 Winograd positions.  Wave w owns output
-// channels 16w..16w+15: M = 16 channels, N = 16 tiles, K = 4 input channels per MFMA, 16 positions x 2 tile
-// halves = 32 accumulators (128 VGPRs).  Every lane therefore ends with all 16 positions of its (channel,
-// tile) pairs in its own registers and the output transform + bias + ReLU (+ the 2x2 max-pool, which is
-// exactly one output tile) needs no exchange.
-//   * A operand  U[ci][co][16]: 64 contiguous bytes per lane straight from L2 into registers (each element is
-//     used by one wave only, LDS would add nothing); next k-step prefetched during the current one.
-//   * B operand  V[ci][tile][16 (+4 pad)]: input chunk of 8 channels streamed by global_load_lds into a 2-stage
-//     LDS ring, transformed by thread (ci, tile) = (t>>5, t&31) with 8 ds_read_b64 + 32 adds + 4 ds_write_b128,
-//     read back as 4 ds_read_b128 per tile half (row stride 80 B: conflict free).
-// WAVES = 4 (default): 256 threads, 64 output channels, chunks of 8 input channels, 2 workgroups per CU.
-// WAVES = 8 (LG_CNN_WIDE=1, layers with >= 128 output channels): 512 threads, 128 output channels share one transformed
-// tile block, chunks of 16 input channels, 1 workgroup per CU -- half the staging + transform work per MFMA.
-template <int CIN, int COUT, int WI, bool POOL, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
-                                                       const float* __restrict__ bias, float* __restrict__ out,
-                                                       const float* __restrict__ zero_tail, int N, int ntb) {
-    constexpr int THREADS = 64 * WAVES;
-    constexpr int KC = 2 * WAVES;                          // input channels per chunk: one (channel, tile) item per thread
+// Workgroup = 256 threads = 32 tiles x 64 output channels x all 16 Winograd positions.  Wave w owns output channels
+// 16w..16w+15: M = 16 channels, N = 16 tiles, K = 4 input channels per MFMA, 16 positions x 2 tile halves = 32
+// accumulators (128 VGPRs); every lane ends with all 16 positions of its (channel, tile) pairs: the output transform +
+// bias + ReLU (+ the 2x2 max-pool = one output tile) needs no exchange.
+//   * A operand  U[ci][co][16]: 64 contiguous bytes per lane from L2 into registers, next k-step prefetched.
+//   * B operand  V[ci][tile][16 (+4 pad)]: the band's haloed rows of a chunk of 8 channels stream into a 2-stage LDS ring
+//     as 16-byte DMA pieces (2-3 per thread and chunk), are transformed by thread (ci, tile) = (t>>5, t&31) and read
+//     back as 4 ds_read_b128 per tile half (row stride 80 B: conflict free).
+template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO>
+__global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict__ in, const float* __restrict__ U,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int N, int ntb) {
+    constexpr int THREADS = 256;
+    constexpr int KC = 8;                                  // input channels per chunk: one (channel, tile) item per thread
     constexpr int KS = KC / 4;                             // MFMA k-steps per chunk
-    constexpr int CB = 16 * WAVES;                         // output channels per workgroup
+    constexpr int CB = 64;                                 // output channels per workgroup
     constexpr int TC = WI / 2, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup (8x8 images: 2)
     constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // workgroups (row bands) per patch
     constexpr int TPB = 32 / PB;                           // tiles of one patch inside the workgroup
     constexpr int TROWS = TPB / TC;                        // tile rows per band
-    constexpr int RH = 2 * TROWS + 2, RW = WI + 2;         // staged input region (halo 1) per channel and patch
-    constexpr int RS = RH * RW, S = PB * RS;
-    constexpr int NIN = (KC * S + THREADS - 1) / THREADS;
+    constexpr int WP = lg_wp(WI), PLANE = lg_plane(WI);
+    constexpr int RH = 2 * TROWS + 2;                      // staged haloed rows per channel and patch
+    constexpr int RS = RH * WP, S = PB * RS;               // floats per (channel, patch) / per channel
+    constexpr int PPC = RS / 4;                            // 16-byte pieces per (channel, patch)
+    constexpr int NPIECE = KC * PB * PPC;
+    constexpr int NIN = (NPIECE + THREADS - 1) / THREADS;
+    constexpr int STAGE = NIN * THREADS * 4;               // floats per input stage
     constexpr int VS = 20;                                 // floats per (ci, tile) row of V: 16 positions + 4 pad
     constexpr int NCB = COUT / CB;
     constexpr int NC = CIN / KC;
-    static_assert(CIN % KC == 0 && COUT % CB == 0 && TPB % TC == 0 && (RW % 2) == 0 && (RS % 2) == 0 && KS % 2 == 0, "shape");
+    static_assert(CIN % KC == 0 && COUT % CB == 0 && TPB % TC == 0 && KS % 2 == 0 && (RS % 4) == 0, "shape");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float s_mem[2 * NIN * THREADS + KC * 32 * VS];
-    float* const s_v = s_mem + 2 * NIN * THREADS;
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * STAGE + KC * 32 * VS];
+    float* const s_v = s_mem + 2 * STAGE;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA bases (M0) stay on the SALU
@@ -354,33 +360,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel
     const int tb = (int)(id / NCB), cb = (int)(id % NCB);
     const int n0 = PB > 1 ? tb * PB : tb / BPP;
     const int band = PB > 1 ? 0 : tb % BPP;
-    const int y0 = band * 2 * TROWS;                       // first output row of the band
+    const int y0 = band * 2 * TROWS;                       // first output row of the band = first staged haloed row
     const int co0 = cb * CB;
 
-    // ---- input staging: chunk-invariant 32-bit byte offsets from a wave-uniform base that advances per chunk
-    //      (global_load_lds saddr + voffset form: issuing a chunk costs ~3 instructions per load).  Conv padding and
-    //      unused slots read zeros from `zero_tail`, a zeroed region >= CIN*WI*WI floats behind the activation buffer:
-    //      their offsets advance with the base like everybody else's and stay inside it.
-    const float* in_n = in + (size_t)n0 * CIN * WI * WI;
-    const unsigned tail_rel = (unsigned)((const char*)zero_tail - (const char*)in_n);
+    // ---- input staging: chunk-invariant byte offsets of this thread's 16-byte pieces from a base that advances per chunk
+    const float* in_n = in + (size_t)n0 * CIN * PLANE;
     unsigned voff[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
         const int e = t + THREADS * j;
-        const int ci = e / S, r = e % S;
-        const int pb = r / RS, r2 = r % RS;
-        const int ry = r2 / RW, rx = r2 % RW;
-        const int gy = y0 - 1 + ry, gx = rx - 1;
-        const bool ok = e < KC * S && gy >= 0 && gy < WI && gx >= 0 && gx < WI && n0 + pb < N;
-        voff[j] = ok ? 4u * (unsigned)(((pb * CIN + ci) * WI + gy) * WI + gx) : tail_rel;
+        const int ci = e / (PB * PPC), r = e % (PB * PPC);
+        const int pb = r / PPC, piece = r % PPC;
+        const bool ok = e < NPIECE && n0 + pb < N;         // slots past the image / patches past the batch: any valid bytes
+        voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
     }
     auto issue_input = [&](int c, int stage) {
-        const char* in_c = (const char*)(in_n + (size_t)c * KC * WI * WI);
-        float* sb = s_mem + stage * (NIN * THREADS);
+        const char* in_c = (const char*)(in_n + (size_t)c * KC * PLANE);
+        float* sb = s_mem + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < NIN; j++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in_c + voff[j]),
-                                             (__attribute__((address_space(3))) void*)(sb + THREADS * j + 64 * wave), 4, 0, 0);
+        for (int j = 0; j < NIN; j++) LG_DMA16(in_c + voff[j], sb + 4 * (THREADS * j + 64 * wave));
     };
     // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co]
     const float* u_lane = U + ((size_t)(lane >> 4) * COUT + co0 + 16 * wave + (lane & 15)) * 16;
@@ -393,7 +391,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel
     const int tci = t >> 5, tau = t & 31;
     const int tpb = tau / TPB, ttl = tau % TPB;
     const int ttr = ttl / TC, ttc = ttl % TC;
-    const int tsrc = tci * S + tpb * RS + (2 * ttr) * RW + 2 * ttc;
+    const int tsrc = tci * S + tpb * RS + (2 * ttr) * WP + 2 * ttc;
     float* const tdst = s_v + (tci * 32 + tau) * VS;
     const float* const vsrc = s_v + ((lane >> 4) * 32 + (lane & 15)) * VS;
 
@@ -436,42 +434,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel
         __syncthreads();                                   // vmcnt(0): input(c) + ab[0] landed; V / other stage free
         load_u(KS * c + 1, ab[1]);
         if (c + 1 < NC) issue_input(c + 1, (c + 1) & 1);
-        {   // V = B^T d B for (tci, tau)
-            const float* sp = s_mem + (c & 1) * (NIN * THREADS) + tsrc;
-            // packed-f32 form: rows as (lo, hi) pairs; the column step folds its negations / half selections into
-            // v_pk_add_f32 modifiers instead of moves
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 dl[4], dh[4];
+        {   // V = B^T d B for (tci, tau): plain v_add / v_sub (a packed add costs 2x a plain one beside f32 MFMA: no gain)
+            const float* sp = s_mem + (c & 1) * STAGE + tsrc;
+            float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 // plain float reads (merged into ds_read2_b64): a float2-typed read makes hipcc drain vmcnt, i.e. the
-                // next chunk's global_load_lds prefetch, in front of it
-                dl[i] = (f32x2){sp[i * RW], sp[i * RW + 1]};
-                dh[i] = (f32x2){sp[i * RW + 2], sp[i * RW + 3]};
+                // next chunk's DMA prefetch, in front of it
+                d[i][0] = sp[i * WP]; d[i][1] = sp[i * WP + 1]; d[i][2] = sp[i * WP + 2]; d[i][3] = sp[i * WP + 3];
             }
-            f32x2 tl[4], th[4];
-            tl[0] = dl[0] - dl[2]; th[0] = dh[0] - dh[2];
-            tl[1] = dl[1] + dl[2]; th[1] = dh[1] + dh[2];
-            tl[2] = dl[2] - dl[1]; th[2] = dh[2] - dh[1];
-            tl[3] = dl[1] - dl[3]; th[3] = dh[1] - dh[3];
+            float r[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                r[0][j] = d[0][j] - d[2][j];
+                r[1][j] = d[1][j] + d[2][j];
+                r[2][j] = d[2][j] - d[1][j];
+                r[3][j] = d[1][j] - d[3][j];
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                // column step in two instructions per row (hipcc does not fold the half selections into op_sel itself):
-                //   v01 = (t0 - t2, t1 + t2): src1 = th.lo for both lanes, negated in the low lane
-                //   v23 = (t2 - t1, t1 - t3): src0 = th, src1 = tl.hi for both lanes; low lane -src1, high lane -src0
-                f32x2 v01, v23;
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
-                    : "=v"(v01) : "v"(tl[i]), "v"(th[i]));
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]"
-                    : "=v"(v23) : "v"(th[i]), "v"(tl[i]));
-                *reinterpret_cast<f32x2*>(tdst + 4 * i) = v01;
-                *reinterpret_cast<f32x2*>(tdst + 4 * i + 2) = v23;
+                f32x4 v = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
+                *reinterpret_cast<f32x4*>(tdst + 4 * i) = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V visible; does not drain the prefetches
-        // A operand of k-step ksl + 1 (the next chunk's first one at the end), requested behind the first MFMAs of step
-        // ksl >= 1 into the buffer step ksl - 1 has released: hipcc waits with vmcnt(0) for the buffer in use, and sinks
-        // an unpinned prefetch to the loop end where the barrier's vmcnt(0) exposes it
 #pragma unroll
         for (int ksl = 0; ksl < KS; ksl++)
             mfma_step(ksl, ab[ksl & 1], [&] {
@@ -482,8 +468,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel
             });
     }
 
-    // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile), planar NCHW store
+    // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile); interior of the haloed output plane
     constexpr int WO = POOL ? WI / 2 : WI;
+    constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
+    constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
+    constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
     const int etau0 = lane & 15;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -505,253 +494,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void lg_wino_kernel
             const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
             const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
             if (n < N) {
-                float* o = out + (size_t)n * COUT * WO * WO + (size_t)co * WO * WO;
+                float* o = out + ((size_t)n * COUT + co) * OPL + OO;
                 if (POOL) {
-                    o[trg * WO + tcg] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)), 0.0f);
+                    o[trg * OP + tcg] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)), 0.0f);
                 } else {
-                    *reinterpret_cast<float2*>(o + (2 * trg) * WO + 2 * tcg) = make_float2(fmaxf(y00, 0.f), fmaxf(y01, 0.f));
-                    *reinterpret_cast<float2*>(o + (2 * trg + 1) * WO + 2 * tcg) = make_float2(fmaxf(y10, 0.f), fmaxf(y11, 0.f));
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the Winograd layer (LG_CNN_WS_KC=8; measured SLOWER than the lock-step kernel above, kept
-// as the documented experiment with its ablation switches).  The kernel above alternates "transform a
-// chunk" and "64 MFMAs" in every wave, so the matrix pipe idles whenever both workgroups of a CU transform or
-// wait at a barrier together (measured 0.57-0.60 of the f32 MFMA peak).  Here a persistent workgroup of 512
-// threads per CU is split by role:
-//   waves 4..7 (producers): stream the input chunks by global_load_lds and write V = B^T d B into a 2-stage LDS ring,
-//                           one chunk ahead of the consumers, across work-item boundaries;
-//   waves 0..3 (consumers): nothing but operand fetches and MFMAs (16 output channels x 32 tiles x 16 positions
-//                           each, as above), B operands of the next half k-step requested before the MFMAs of the
-//                           current one, A operands of the next k-step prefetched from L2;
-// one s_barrier per chunk hands a V stage over (consumers arrive with an LDS-only wait, so their A prefetch stays
-// in flight).  A work item = (32-tile block, 64-channel block); a workgroup takes a contiguous range of items, so the
-// channel blocks of one input band follow each other on one CU (input band hot in L2) and prologue / epilogue
-// latencies are paid once per workgroup / overlapped by the producers' run-ahead.
-template <int CIN, int COUT, int WI, bool POOL, int KC>
-__global__ __launch_bounds__(512, 1) void lg_wino_ws_kernel(const float* __restrict__ in, const float* __restrict__ U,
-                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                          int N, int ntb) {
-    constexpr int TC = WI / 2, TP = TC * TC;
-    constexpr int PB = TP >= 32 ? 1 : 32 / TP;
-    constexpr int BPP = TP >= 32 ? TP / 32 : 1;
-    constexpr int TPB = 32 / PB;
-    constexpr int TROWS = TPB / TC;
-    constexpr int RH = 2 * TROWS + 2, RW = WI + 2;
-    constexpr int RS = RH * RW, S = PB * RS;
-    constexpr int NIN = (KC * S + 255) / 256;
-    constexpr int INB = NIN * 256;                         // floats per input stage
-    constexpr int VS = 20;
-    constexpr int VB = KC * 32 * VS;                       // floats per V stage
-    constexpr int NCB = COUT / 64;
-    constexpr int NC = CIN / KC;                           // chunks per work item
-    constexpr int KS = KC / 4;                             // MFMA k-steps per chunk
-    static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (KS % 2) == 0 && KC % 8 == 0, "shape");
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int RI = 3;                                  // input ring: chunks sq+2, sq+3 in flight while sq+1 is transformed
-    __shared__ __attribute__((aligned(16))) float s_mem[RI * INB + 2 * VB];
-    float* const s_v = s_mem + RI * INB;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const long long total = (long long)ntb * NCB;
-    const int it0 = (int)(total * blockIdx.x / gridDim.x), it1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
-    const int nitems = it1 - it0;
-    if (nitems <= 0) return;
-    const int nseq = nitems * NC;                          // chunks this workgroup streams
-
-    if (wave >= 4) {
-        // ================================================================= producers
-        const int pt = t - 256, pw = wave - 4;
-        int off_in[NIN];
-        const float* in_n = in;
-        auto issue = [&](int sq) {
-            const int c = sq % NC;
-            if (c == 0) {                                  // new work item: staging offsets of its band
-                const int tb = (it0 + sq / NC) / NCB;
-                const int n0 = PB > 1 ? tb * PB : tb / BPP;
-                const int y0 = (PB > 1 ? 0 : tb % BPP) * 2 * TROWS;
-#pragma unroll
-                for (int j = 0; j < NIN; j++) {
-                    const int e = pt + 256 * j;
-                    const int ci = e / S, r = e % S;
-                    const int pb = r / RS, r2 = r % RS;
-                    const int ry = r2 / RW, rx = r2 % RW;
-                    const int gy = y0 - 1 + ry, gx = rx - 1;
-                    const bool ok = e < KC * S && gy >= 0 && gy < WI && gx >= 0 && gx < WI && n0 + pb < N;
-                    off_in[j] = ok ? ((pb * CIN + ci) * WI + gy) * WI + gx : -1;
-                }
-                in_n = in + (size_t)n0 * CIN * WI * WI;
-            }
-            const float* in_c = in_n + (size_t)c * KC * WI * WI;
-            float* sb = s_mem + (sq % RI) * INB;
-#pragma unroll
-            for (int j = 0; j < NIN; j++) {
-                const float* src = off_in[j] >= 0 ? in_c + off_in[j] : lg_zero_pad;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sb + 256 * j + 64 * pw), 4, 0, 0);
-            }
-        };
-        const int tau = pt & 31;
-        const int tpb = tau / TPB, ttl = tau % TPB;
-        const int tsrc0 = tpb * RS + (2 * (ttl / TC)) * RW + 2 * (ttl % TC);
-        auto transform = [&](int sq) {                     // V = B^T d B for (channel, tile) = (pt >> 5 [+8], pt & 31)
-#pragma unroll
-            for (int it = 0; it < KC / 8; it++) {
-                const int tci = (pt >> 5) + 8 * it;
-                const float* sp = s_mem + (sq % RI) * INB + tci * S + tsrc0;
-                float d[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {              // plain float reads (see lg_wino_kernel)
-                    d[i][0] = sp[i * RW]; d[i][1] = sp[i * RW + 1]; d[i][2] = sp[i * RW + 2]; d[i][3] = sp[i * RW + 3];
-                }
-                float r[4][4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    r[0][j] = d[0][j] - d[2][j];
-                    r[1][j] = d[1][j] + d[2][j];
-                    r[2][j] = d[2][j] - d[1][j];
-                    r[3][j] = d[1][j] - d[3][j];
-                }
-                float* dst = s_v + (sq & 1) * VB + (tci * 32 + tau) * VS;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    f32x4 v = {r[i][0] - r[i][2], r[i][1] + r[i][2], r[i][2] - r[i][1], r[i][1] - r[i][3]};
-                    *reinterpret_cast<f32x4*>(dst + 4 * i) = v;
-                }
-            }
-        };
-        // HBM latency (2-3 us) exceeds one chunk of MFMA time (~1 us): the input runs two chunks ahead of the transform.
-        // Loads return in order, so "at most NIN outstanding" = everything but the newest chunk has landed.
-        issue(0);
-        if (1 < nseq) issue(1);
-        if (2 < nseq) {
-            issue(2);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NIN) : "memory");   // input(0) visible
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        transform(0);
-        if (2 < nseq) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");  // V(0), input(1)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll 1
-        for (int sq = 0; sq < nseq; sq++) {                // consumers work on V(sq)
-            const bool more_in = sq + 3 < nseq;
-            if (more_in && !(LG_WS_EXP & 8)) issue(sq + 3);   // stage sq % 3: its last reader was transform(sq)
-            if (sq + 1 < nseq && !(LG_WS_EXP & 4)) transform(sq + 1);          // V stage (sq+1) & 1: its last readers were the MFMAs of sq-1
-            if (more_in) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");  // input(sq+2) landed
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    } else {
-        // ================================================================= consumers
-        const float* const vsrc = s_v + ((lane >> 4) * 32 + (lane & 15)) * VS;
-        const float* const u_lane = U + ((size_t)(lane >> 4) * COUT + 16 * wave + (lane & 15)) * 16;
-        f32x4 acc[16][2];
-        f32x4 ab[2][4];                                    // A operand ring (k-step parity)
-        f32x4 bb[2][4];                                    // B operand ring (half k-step parity)
-        auto load_u = [&](int cb, int ks, f32x4 (&a)[4]) { // ks = k-step inside the item (4 input channels each)
-            const f32x4* p = reinterpret_cast<const f32x4*>(u_lane + ((size_t)ks * 4 * COUT + cb * 64) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = p[q];
-        };
-        auto load_b = [&](int stage, int ksl, int h, f32x4 (&b)[4]) {
-            const float* vb = vsrc + stage * VB + (ksl * 4 * 32 + 16 * h) * VS;
-#pragma unroll
-            for (int q = 0; q < 4; q++) b[q] = *reinterpret_cast<const f32x4*>(vb + 4 * q);
-        };
-        // one chunk: KS k-steps x 2 tile halves; `first` zero-initialises the accumulators with the first k-step
-        auto chunk = [&](auto first_tag, int stage, int cb, int c, int cb_next, bool more) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            load_b(stage, 0, 0, bb[0]);
-            if (LG_WS_EXP & 2) load_b(stage, 0, 1, bb[1]);
-#pragma unroll
-            for (int ksl = 0; ksl < KS; ksl++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int u = 2 * ksl + h;
-                    if (u + 1 < 2 * KS && !(LG_WS_EXP & 2)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_b(stage, (u + 1) >> 1, (u + 1) & 1, bb[(u + 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            if (FIRST && ksl == 0)
-                                acc[4 * q + e][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    ab[ksl & 1][q][e], bb[u & 1][q][e], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                            else
-                                acc[4 * q + e][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[ksl & 1][q][e], bb[u & 1][q][e],
-                                                                                           acc[4 * q + e][h], 0, 0, 0);
-                        }
-                        if (q == 0 && h == 0) {
-                            // A operand of the next k-step (next chunk / next item at the end), behind the wait for
-                            // this step's A so that wait cannot catch it
-                            __builtin_amdgcn_sched_barrier(0);
-                            // (unconditional, clamped at the very end: a branch here makes hipcc wait vmcnt(0) at the join)
-                            const int ksn = c * KS + ksl + 1;
-                            const bool within = ksn < NC * KS;
-                            if (!(LG_WS_EXP & 1)) load_u(within || !more ? cb : cb_next, within ? ksn : 0, ab[(ksl + 1) & 1]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done with this V stage
-        };
-
-        load_u(it0 % NCB, 0, ab[0]);
-        if (LG_WS_EXP & 1) load_u(it0 % NCB, 1, ab[1]);
-        asm volatile("s_barrier" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        constexpr int WO = POOL ? WI / 2 : WI;
-        int sq = 0;
-#pragma unroll 1
-        for (int item = it0; item < it1; item++) {
-            const int tb = item / NCB, cb = item % NCB;
-            const int cb_next = (item + 1) % NCB;
-            const bool more = item + 1 < it1;
-            const int co_l = cb * 64 + 16 * wave + 4 * (lane >> 4);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co_l);
-            chunk(std::true_type{}, sq & 1, cb, 0, cb_next, more);
-            sq++;
-#pragma unroll 1
-            for (int c = 1; c < NC; c++, sq++) chunk(std::false_type{}, sq & 1, cb, c, cb_next, more);
-
-            // ---- epilogue: Y = A^T M A, bias, ReLU (+ max over the 2x2 tile), planar NCHW store
-            const int n0 = PB > 1 ? tb * PB : tb / BPP;
-            const int band = PB > 1 ? 0 : tb % BPP;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int etau = 16 * h + (lane & 15);
-                const int epb = etau / TPB, etl = etau % TPB;
-                const int n = n0 + epb;
-                const int trg = band * TROWS + etl / TC, tcg = etl % TC;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float s0[4], s1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float m0 = acc[j][h][r], m1 = acc[4 + j][h][r], m2 = acc[8 + j][h][r], m3 = acc[12 + j][h][r];
-                        s0[j] = m0 + m1 + m2;
-                        s1[j] = m1 - m2 - m3;
-                    }
-                    const float y00 = s0[0] + s0[1] + s0[2] + bv[r], y01 = s0[1] - s0[2] - s0[3] + bv[r];
-                    const float y10 = s1[0] + s1[1] + s1[2] + bv[r], y11 = s1[1] - s1[2] - s1[3] + bv[r];
-                    if (n < N) {
-                        float* o = out + (size_t)n * COUT * WO * WO + (size_t)(co_l + r) * WO * WO;
-                        if (POOL) {
-                            o[trg * WO + tcg] = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)), 0.0f);
-                        } else {
-                            *reinterpret_cast<float2*>(o + (2 * trg) * WO + 2 * tcg) = make_float2(fmaxf(y00, 0.f), fmaxf(y01, 0.f));
-                            *reinterpret_cast<float2*>(o + (2 * trg + 1) * WO + 2 * tcg) = make_float2(fmaxf(y10, 0.f), fmaxf(y11, 0.f));
-                        }
-                    }
+                    float* o0 = o + (2 * trg) * OP + 2 * tcg;    // (interior pixels start at an odd column: dword stores)
+                    o0[0] = fmaxf(y00, 0.f); o0[1] = fmaxf(y01, 0.f);
+                    o0[OP] = fmaxf(y10, 0.f); o0[OP + 1] = fmaxf(y11, 0.f);
                 }
             }
         }
@@ -874,32 +623,14 @@ void launch_conv(const float* in, const LgCnn* c, float* out, int N, hipStream_t
     constexpr int BANDS = cfg.wi / ROWS > 0 ? cfg.wi / ROWS : 1;
     static_assert(ROWS <= cfg.wi && cfg.wi % ROWS == 0, "tile rows must divide the image");
     const int grid = N * BANDS * (cfg.cout / (64 * CP));
-    hipLaunchKernelGGL((lg_conv3x3_kernel<cfg.cin, cfg.cinp, cfg.cout, cfg.wi, cfg.pool, KC, PP, CP>), dim3(grid), dim3(256), 0,
-                       s, in, c->wconv[L], c->bconv[L], out);
+    hipLaunchKernelGGL((lg_conv3x3_kernel<cfg.cin, cfg.cinp, cfg.cout, cfg.wi, cfg.pool, L != 5, KC, PP, CP>), dim3(grid),
+                       dim3(256), 0, s, in, c->wconv[L], c->bconv[L], out, c->zeros);
 }
 
-// layer 0 of any encoder (9 input channels -> 64 or 128 padded output channels at 32x32): direct implicit GEMM,
-// one workgroup per (patch, 64 channels) walking the four bands (LG_CNN_L0_BANDS=1: the per-band generic kernel, A/B)
+// layer 0 of any encoder (9 input channels -> 64 or 128 padded output channels at 32x32): direct implicit GEMM
 template <int COUT>
 void launch_conv0(const float* in, const LgCnn* c, float* out, int N, hipStream_t s) {
-    if (getenv("LG_CNN_L0_BANDS")) {
-        const int grid = N * 4 * (COUT / 64);   // PP = 4: 8 rows per workgroup -> 4 bands
-        hipLaunchKernelGGL((lg_conv3x3_kernel<9, 10, COUT, 32, false, 10, 4, 1>), dim3(grid), dim3(256), 0, s, in, c->wconv[0],
-                           c->bconv[0], out);
-        return;
-    }
-    hipLaunchKernelGGL((lg_conv0_kernel<COUT>), dim3(N * (COUT / 64)), dim3(256), 0, s, in, c->wconv[0], c->bconv[0], out);
-}
-
-template <int L, int KC>
-void launch_wino_ws(const float* in, const LgCnn* c, float* out, int N, hipStream_t s, int num_cu) {
-    constexpr LayerCfg cfg = kLayers[L];
-    constexpr int TP = (cfg.wi / 2) * (cfg.wi / 2);
-    const int ntb = TP >= 32 ? N * (TP / 32) : (N + 32 / TP - 1) / (32 / TP);
-    const long long total = (long long)ntb * (cfg.cout / 64);
-    const int grid = (int)(total < num_cu ? total : num_cu);   // persistent: one workgroup per CU
-    hipLaunchKernelGGL((lg_wino_ws_kernel<cfg.cin, cfg.cout, cfg.wi, cfg.pool, KC>), dim3(grid), dim3(512), 0, s, in,
-                       c->uwino[L], c->bconv[L], out, N, ntb);
+    hipLaunchKernelGGL((lg_conv0_kernel<COUT>), dim3(N * (COUT / 64)), dim3(256), 0, s, in, c->wconv[0], c->bconv[0], out, c->zeros);
 }
 
 // Winograd layer shapes of the four encoder configurations of the reference's sweep (train_model_mlflow.py:177-182;
@@ -917,30 +648,19 @@ bool wino_supported(int cin, int cout, int wi, bool pool) {
     return false;
 }
 
-// 128 output channels per workgroup (WAVES = 8): the layers of the default encoder with >= 128 output channels
-#define LG_WINO_WIDE_SHAPES(X) X(64, 128, 16, false) X(128, 128, 16, true) X(128, 256, 8, false) X(256, 256, 8, true)
-
-bool launch_wino_rt(int cin, int cout, int wi, bool pool, const float* in, const float* U, const float* bias, float* out,
-                    const float* zero_tail, int N, hipStream_t s) {
+// out_halo: the next layer is a convolution (haloed plane); false: the head reads dense [C][npix]
+bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U, const float* bias,
+                    float* out, int N, hipStream_t s) {
     const int tp = (wi / 2) * (wi / 2);
     const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
-    if (getenv("LG_CNN_WIDE")) {
-        const int gridw = ntb * (cout / 128);
-#define X(CI, CO, W_, P)                                                                                           \
-    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                        \
-        hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P, 8>), dim3(gridw), dim3(512), 0, s, in, U, bias, out, zero_tail, \
-                           N, ntb);                                                                                \
-        return true;                                                                                               \
-    }
-        LG_WINO_WIDE_SHAPES(X)
-#undef X
-    }
     const int grid = ntb * (cout / 64);
-#define X(CI, CO, W_, P)                                                                                           \
-    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                        \
-        hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P>), dim3(grid), dim3(256), 0, s, in, U, bias, out, zero_tail, N, \
-                           ntb);                                                                                   \
-        return true;                                                                                               \
+#define X(CI, CO, W_, P)                                                                                              \
+    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
+        if (out_halo)                                                                                                 \
+            hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P, true>), dim3(grid), dim3(256), 0, s, in, U, bias, out, N, ntb);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((lg_wino_kernel<CI, CO, W_, P, false>), dim3(grid), dim3(256), 0, s, in, U, bias, out, N, ntb); \
+        return true;                                                                                                  \
     }
     LG_WINO_SHAPES(X)
 #undef X
@@ -951,10 +671,10 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, const float* in, const
 
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
-    for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); }
+    for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); F(c->act[i]); }
     F(c->att_w); F(c->ca_w1); F(c->ca_b1); F(c->ca_w2); F(c->ca_b2);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
-    F(c->act[0]); F(c->act[1]);
+    F(c->in_halo); F(c->zeros);
     c->capN = 0;
     c->loaded = false;
 }
@@ -1093,69 +813,83 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
         rc = upload(&c->fcb[L], bt, err);
         if (rc) return rc;
     }
+    {   // zeroed plane: padding channel of layer 0, unused staging slots
+        std::vector<float> z(4096, 0.0f);
+        int rc = upload(&c->zeros, z, err);
+        if (rc) return rc;
+    }
+    // A/B and test switches of the standard encoder, read when the model is loaded (not on the per-call path):
+    // LG_CNN_DIRECT=1 direct implicit GEMM for every layer; LG_CNN_WINO_MASK=<bits> bit L = layer L on Winograd
+    c->wino_mask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
+    if (const char* e = getenv("LG_CNN_WINO_MASK")) c->wino_mask = atoi(e) & 0x3e;
     c->loaded = true;
     return LG_OK;
 }
 
-static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err);
 
-// Slices share the activation workspace (the 32-bit staging offsets of lg_wino_kernel reach 4 GiB: at most ~2 GiB of
-// activations per buffer and slice, i.e. 8192 patches of the standard model).
-int lg_cnn_run(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
+size_t lg_cnn_halo_patch_floats(void) { return (size_t)9 * lg_plane(32); }
+
+// activation buffers, one per layer (fixed geometry: the zero halos are written once, at allocation)
+static int ensure_act(LgCnn* c, int N, hipStream_t s, std::string* err) {
+    if (N <= c->capN) return LG_OK;
+    hipStreamSynchronize(s);
+    for (int i = 0; i < 8; i++)
+        if (c->act[i]) { hipFree(c->act[i]); c->act[i] = nullptr; }
+    if (c->in_halo) { hipFree(c->in_halo); c->in_halo = nullptr; }
+    c->capN = 0;
+    bool ok = true;
+    for (int L = 0; L < c->n_layers && ok; L++) {
+        const RtLayer& l = c->layers[L];
+        const int wo = l.pool ? l.wi / 2 : l.wi;
+        const size_t per = (size_t)l.coutp * (L + 1 < c->n_layers ? lg_plane(wo) : wo * wo);
+        c->act_per[L] = per;
+        ok = hipMalloc((void**)&c->act[L], (size_t)N * per * sizeof(float)) == hipSuccess &&
+             hipMemsetAsync(c->act[L], 0, (size_t)N * per * sizeof(float), s) == hipSuccess;
+    }
+    ok = ok && hipMalloc((void**)&c->in_halo, (size_t)N * lg_cnn_halo_patch_floats() * sizeof(float)) == hipSuccess &&
+         hipMemsetAsync(c->in_halo, 0, (size_t)N * lg_cnn_halo_patch_floats() * sizeof(float), s) == hipSuccess;
+    if (!ok) {
+        *err = "lg_cnn_forward: activation workspace allocation failed";
+        return LG_ERR_NOMEM;
+    }
+    c->capN = N;
+    return LG_OK;
+}
+
+static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err);
+
+// Slices bound the activation workspace (0.8 MB per patch for the standard model): at most 8192 patches at a time.
+int lg_cnn_run(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err) {
     if (!c->loaded) { *err = "no model"; return LG_ERR_NO_MODEL; }
-    const int max_slice = (int)std::max<size_t>(64, ((size_t)1 << 31) / (c->act_per_patch * sizeof(float)));
+    const int max_slice = 8192;
+    const size_t pstride = haloed_in ? lg_cnn_halo_patch_floats() : (size_t)9 * 1024;
     for (int off = 0; off < N; off += max_slice) {
         const int n = N - off < max_slice ? N - off : max_slice;
-        int rc = lg_cnn_run_slice(c, patches + (size_t)off * 9 * 1024, n, logits + off, s, err);
+        int rc = lg_cnn_run_slice(c, patches + (size_t)off * pstride, haloed_in, n, logits + off, s, err);
         if (rc) return rc;
     }
     return LG_OK;
 }
 
-static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits, hipStream_t s, std::string* err) {
-    const size_t per = c->act_per_patch;
-    const size_t tail = per + 1024;   // zeroed floats behind each buffer: >= cin * width^2 of any layer
-    if (N > c->capN) {
-        hipStreamSynchronize(s);
-        if (c->act[0]) hipFree(c->act[0]);
-        if (c->act[1]) hipFree(c->act[1]);
-        c->act[0] = c->act[1] = nullptr;
-        if (hipMalloc((void**)&c->act[0], ((size_t)N * per + tail) * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&c->act[1], ((size_t)N * per + tail) * sizeof(float)) != hipSuccess) {
-            *err = "lg_cnn_forward: activation workspace allocation failed";
-            c->capN = 0;
-            return LG_ERR_NOMEM;
-        }
-        hipMemsetAsync(c->act[0] + (size_t)N * per, 0, tail * sizeof(float), s);
-        hipMemsetAsync(c->act[1] + (size_t)N * per, 0, tail * sizeof(float), s);
-        c->capN = N;
+static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err) {
+    int rc = ensure_act(c, N, s, err);
+    if (rc) return rc;
+    const float* x = patches;
+    if (!haloed_in) {   // the C-ABI's dense [N][9][32][32] patches -> haloed planes
+        hipLaunchKernelGGL(lg_repack_kernel, dim3((unsigned)(N * 9)), dim3(256), 0, s, patches, c->in_halo, (long long)N * 9);
+        x = c->in_halo;
     }
-    float *A = c->act[0], *B = c->act[1];
-    const size_t tail_off = (size_t)c->capN * per;   // the zeroed tail sits behind BOTH buffers at the same offset
-    if (c->layers[0].coutp == 64) launch_conv0<64>(patches, c, A, N, s);
-    else launch_conv0<128>(patches, c, A, N, s);
-    float* cur = A;
-    float* nxt = B;
+    if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
+    else launch_conv0<128>(x, c, c->act[0], N, s);
+    const float* cur = c->act[0];
     if (c->standard) {
-        // Winograd F(2x2,3x3) for layers 1..5 (2.25x fewer MFMA flops); LG_CNN_DIRECT=1 selects the direct implicit GEMM
-        // for all layers, LG_CNN_WINO_MASK=<bits> a per-layer choice (bit L = layer L on Winograd), LG_CNN_WS_KC=8 the
-        // producer/consumer form (4.45 vs 4.01 ms per 2560 patches) -- A/B and test switches, read per call.
-        int wmask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
-        if (const char* e = getenv("LG_CNN_WINO_MASK")) wmask = atoi(e) & 0x3e;
-        const int ws_kc = getenv("LG_CNN_WS_KC") ? atoi(getenv("LG_CNN_WS_KC")) : 0;
-        static const int num_cu = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            if (const char* e = getenv("LG_CNN_WS_GRID")) n = atoi(e);
-            return n > 0 ? n : 256;
-        }();
+        const int wmask = c->wino_mask;
 #define LG_LAYER(L, KC, PP, CP)                                                                                     \
     do {                                                                                                            \
         const RtLayer& l = c->layers[L];                                                                            \
-        if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, nxt, N, s);                                     \
-        else if (ws_kc == 8) launch_wino_ws<L, 8>(cur, c, nxt, N, s, num_cu);                                       \
-        else launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, cur, c->uwino[L], c->bconv[L], nxt, cur + tail_off, N, s); \
-        std::swap(cur, nxt);                                                                                        \
+        if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, c->act[L], N, s);                               \
+        else launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
+        cur = c->act[L];                                                                                            \
     } while (0)
         LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
         LG_LAYER(2, 8, 4, 1);   // 64 -> 128, 16x16
@@ -1166,11 +900,11 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, int N, float* logits
     } else {
         for (int L = 1; L < c->n_layers; L++) {
             const RtLayer& l = c->layers[L];
-            if (!launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, cur, c->uwino[L], c->bconv[L], nxt, cur + tail_off, N, s)) {
+            if (!launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)) {
                 *err = "lg_cnn_forward: unsupported layer shape";
                 return LG_ERR_UNSUPPORTED;
             }
-            std::swap(cur, nxt);
+            cur = c->act[L];
         }
     }
 #define LG_HEAD(F_, NP_)                                                                                              \

@@ -94,7 +94,7 @@ void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth,
                     bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,
                     float* out_info, hipStream_t s);
 void lg_launch_gather(const float* depth, const uint8_t* mask, const float* const* maps_dev, int B, int H, int W, int k,
-                      const int32_t* xy, const int32_t* n, float* patches, hipStream_t s);
+                      const int32_t* xy, const int32_t* n, float* patches, bool haloed, hipStream_t s);
 
 // host-side contour analysis on the bit-packed mask (lg_contour.cpp)
 // returns 1 and fills out[0..4] = angle(rad,(0,pi]), major, minor, cx, cy ; 0 if the mask is empty

@@ -1062,8 +1062,8 @@ __global__ __launch_bounds__(256) void lg_tilekeys_kernel(const float* __restric
 //                  suppress every pixel within Chebyshev distance 2*min_dist of the pick }.
 // Equivalent to the reference's greedy walk over the descending argsort (a pixel is accepted iff its
 // (2d+1)^2 window meets no earlier window, i.e. iff it is > 2d away from every accepted point).
-// One 1024-thread workgroup per frame; per-tile maxima live in LDS and only the <= 6 tiles touched by
-// a new suppression window are recomputed.
+// One 1024-thread workgroup per frame; per-tile maxima live in LDS and only the tiles touched by a new suppression
+// window (<= 8 of 64x16 pixels for the reference's 41x41 window; any number for larger min_distance) are recomputed.
 #define LG_TOPK_T 1024
 #define LG_MAX_TILES 8192
 #define LG_MAX_K 64
@@ -1109,7 +1109,8 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         const int naff = ntx * nty;
         __syncthreads();  // s_cx/s_cy visible; everyone has read s_best
         if (t == 0) s_best = 0;
-        if (t < naff) s_keys[(ty_lo + t / ntx) * tiles_x + tx_lo + t % ntx] = 0;
+        for (int i = t; i < naff; i += LG_TOPK_T)   // any window size: a large min_distance touches > 1024 tiles
+            s_keys[(ty_lo + i / ntx) * tiles_x + tx_lo + i % ntx] = 0;
         __syncthreads();
         // 1024-pixel chunks, 2 per tile.  Loads of up to 12 chunks are issued together (one round trip to L2/HBM
         // instead of one per chunk: each round of the greedy walk is a dependent chain, latency is everything).
@@ -1179,17 +1180,21 @@ void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth,
 // replicate-padded (:392-445); channel 0 depth and channels 2..8 (sdf, approach, flatness, isolation,
 // distance, accessibility, stem) are min-max normalised per patch when max > min; channel 1 = raw mask.
 struct LgGatherMaps { const float* p[7]; };
+// HALO: write the interior of haloed planes [9][34][36] (pixel (y,x) at [y+1][x+1]; the CNN's staging layout, lg_cnn.hip;
+// the halo itself is zeroed once when the workspace is allocated) instead of dense [9][32][32].
+template <bool HALO>
 __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict__ depth,
                                                         const uint8_t* __restrict__ mask, LgGatherMaps maps, int H,
                                                         int W, int k, const int32_t* __restrict__ xy,
                                                         const int32_t* __restrict__ n, float* __restrict__ patches) {
     __shared__ float s_mn[4], s_mx[4];
+    constexpr int PL = HALO ? 34 * 36 : 1024, RP = HALO ? 36 : 32, O0 = HALO ? 37 : 0;
     const int ci = blockIdx.x, frame = blockIdx.y;
     const int t = threadIdx.x;
-    float* outp = patches + ((size_t)frame * k + ci) * 9 * 1024;
+    float* outp = patches + ((size_t)frame * k + ci) * 9 * PL + O0;
     if (ci >= n[frame]) {
         for (int c = 0; c < 9; c++)
-            for (int i = t; i < 1024; i += 256) outp[c * 1024 + i] = 0.0f;
+            for (int i = t; i < 1024; i += 256) outp[c * PL + (i >> 5) * RP + (i & 31)] = 0.0f;
         return;
     }
     const int px = xy[((size_t)frame * k + ci) * 2], py = xy[((size_t)frame * k + ci) * 2 + 1];
@@ -1227,15 +1232,19 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) outp[c * 1024 + t + 256 * q] = v[q];
+        for (int q = 0; q < 4; q++) {
+            const int i = t + 256 * q;
+            outp[c * PL + (i >> 5) * RP + (i & 31)] = v[q];
+        }
     }
 }
 
 void lg_launch_gather(const float* depth, const uint8_t* mask, const float* const* maps_host, int B, int H, int W, int k,
-                      const int32_t* xy, const int32_t* n, float* patches, hipStream_t s) {
+                      const int32_t* xy, const int32_t* n, float* patches, bool haloed, hipStream_t s) {
     LgGatherMaps gm;
     for (int i = 0; i < 7; i++) gm.p[i] = maps_host[i];
-    hipLaunchKernelGGL(lg_gather_kernel, dim3(k, B), dim3(256), 0, s, depth, mask, gm, H, W, k, xy, n, patches);
+    if (haloed) hipLaunchKernelGGL(lg_gather_kernel<true>, dim3(k, B), dim3(256), 0, s, depth, mask, gm, H, W, k, xy, n, patches);
+    else hipLaunchKernelGGL(lg_gather_kernel<false>, dim3(k, B), dim3(256), 0, s, depth, mask, gm, H, W, k, xy, n, patches);
 }
 
 // ============================================================================ training-sample harvesting

@@ -56,6 +56,46 @@ def test_leaf_statistics_and_selection(L, shape, seed):
         np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-4, atol=1e-7)
 
 
+# Measured bound of the one deliberate semantic substitution on this path: the HIP clutter
+# field is the EXACT Euclidean distance, the reference's is skfmm's second-order fast-marching approximation
+# (leaf_scorer.py:66-71), restated in oracle/lg_oracle.c::lg_fmm_distance.  Over 120 scenes (40 seeds x 720p / native /
+# 1080p, /tmp sweep of round 2): arg-max moved by <= 1 px, |d clutter_score| <= 2.7e-4, 0 different leaf ids, 0 different
+# tall-leaf lists.  The bounds asserted here leave a 2-4x margin over that.
+_FMM_ARGMAX_PX = 2.0
+_FMM_CLUTTER_ABS = 1e-3
+
+
+@pytest.mark.parametrize("shape", [(720, 1280), (1080, 1440), (1080, 1920)])
+def test_hip_clutter_extrema_vs_restated_fmm(L, shape):
+    H, W = shape
+    ols = L.OptimalLeafSelector("cuda:0")
+    worst_px, worst_cl, n_sel = 0.0, 0.0, 0
+    for seed in range(40, 52):
+        labels, depth, P = O.synthetic_scene(H, W, seed)
+        ols.set_camera_params(P)
+        g = ols.select_optimal_leaf(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda(), return_debug=True)
+        ref = O.RefOptimalLeafSelector("fmm")          # the reference's field semantics
+        ref.set_camera_params(P)
+        r = ref.select_optimal_leaf(labels, depth, return_debug=True)
+        if r is None:
+            assert g is None
+            continue
+        (exp, dbg), (got, gdbg) = r, g
+        (gmn, gmx), (fmn, fmx) = gdbg["extrema"], dbg["extrema"]
+        assert tuple(gmn) == tuple(int(v) for v in fmn)                 # first leaf pixel either way
+        worst_px = max(worst_px, float(np.hypot(gmx[0] - fmx[0], gmx[1] - fmx[1])))
+        assert [c["leaf_id"] for c in gdbg["candidates"]] == [c["leaf_id"] for c in dbg["candidates"]]
+        for a, b in zip(gdbg["candidates"], dbg["candidates"]):
+            worst_cl = max(worst_cl, abs(a["scores"][0] - b["scores"][0]))
+            np.testing.assert_allclose(a["scores"][1:], b["scores"][1:], rtol=1e-4, atol=1e-7)   # distance, visibility
+        assert got == exp, f"seed {seed}: HIP (EDT) picks leaf {got}, restated FMM semantics pick {exp}"
+        assert ols.get_tall_leaves() == ref.get_tall_leaves()
+        n_sel += 1
+    assert n_sel >= 8
+    assert worst_px <= _FMM_ARGMAX_PX, worst_px
+    assert worst_cl <= _FMM_CLUTTER_ABS, worst_cl
+
+
 def test_leaf_selection_edge_cases(L):
     ols = L.OptimalLeafSelector("cuda:0")
     P = np.array([[300.0, 0, 100, -20], [0, 300, 80, 0], [0, 0, 1, 0]])

@@ -222,6 +222,18 @@ def test_candidates_vs_oracle_bit_exact(sel, seed):
     assert got == ref
 
 
+def test_candidates_large_min_distance(sel):
+    """min_distance is caller-controlled (_get_candidate_points(min_distance=...), grasp_point_selector.py:447): a suppression
+    window wider than 1024 tiles (2*300+1 px at 1080p) must still equal the oracle's greedy walk; a negative one is rejected."""
+    rng = np.random.default_rng(11)
+    H, W = 1080, 1920
+    sm = rng.random((H, W), dtype=np.float32)
+    valid = np.ones((H, W), bool)
+    for k, md in ((8, 300), (6, 200), (20, 64)):
+        assert sel._get_candidate_points(sm, valid, k, md) == O.RefGraspPointSelector()._get_candidate_points(sm, valid, k, md), (k, md)
+    assert sel._get_candidate_points(sm, valid, 5, -3) == []   # LG_ERR_INVALID -> logged, empty list
+
+
 def test_candidates_fall_through(sel):
     sm = np.zeros((40, 40), np.float32)
     sm[20, 20], sm[20, 25] = 1.0, 0.9
@@ -262,33 +274,31 @@ def test_cnn_vs_reference_golden(sel, golden):
 
 
 def test_cnn_winograd_matches_direct(sel, monkeypatch):
-    """Winograd F(2x2,3x3) conv layers (default) vs the direct implicit-GEMM kernels, layer by layer and all together,
-    for even / odd / single patch counts (8x8 layers put two patches in one workgroup)."""
+    """Winograd conv layers (default) vs the direct implicit-GEMM kernels, layer by layer and all together, for even / odd /
+    single patch counts (8x8 layers put several patches into one workgroup).  The switches are read when the model is
+    loaded (lg_cnn_load), never on the per-call path."""
     params = O.cnn_closed_form_params(seed=0)
-    sel.set_cnn_state_dict(params)
     x = torch.from_numpy(O.synthetic_patches(41, seed=5)).cuda()
     monkeypatch.setenv("LG_CNN_DIRECT", "1")
+    sel.set_cnn_state_dict(params)
     want = sel.cnn_forward(x).cpu().numpy()
     monkeypatch.delenv("LG_CNN_DIRECT")
     for mask in (2, 4, 8, 16, 32, 0x3e):
         monkeypatch.setenv("LG_CNN_WINO_MASK", str(mask))
+        sel.set_cnn_state_dict(params)
         got = sel.cnn_forward(x).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6, err_msg=f"wino mask {mask}")
         for n in (1, 2, 7):
             np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), got[:n], err_msg=f"mask {mask} n {n}")
     monkeypatch.delenv("LG_CNN_WINO_MASK")
+    # the older F(2x2,3x3) Winograd form of every layer (LG_CNN_F23=1), kept as the second opinion on the default F(4x4,3x3)
+    monkeypatch.setenv("LG_CNN_F23", "1")
+    sel.set_cnn_state_dict(params)
+    got23 = sel.cnn_forward(x).cpu().numpy()
+    np.testing.assert_allclose(got23, want, rtol=2e-5, atol=2e-6, err_msg="F(2x2,3x3)")
+    monkeypatch.delenv("LG_CNN_F23")
+    sel.set_cnn_state_dict(params)
     np.testing.assert_allclose(sel.cnn_forward(x).cpu().numpy(), O.cnn_forward(params, x.cpu().numpy()), rtol=1e-4, atol=1e-5)
-    # the producer/consumer (persistent) form of the same layers: identical k order per accumulator -> identical bits
-    default = sel.cnn_forward(x).cpu().numpy()
-    monkeypatch.setenv("LG_CNN_WS_KC", "8")
-    for n in (41, 1, 2, 7):
-        np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"ws kernel n {n}")
-    monkeypatch.delenv("LG_CNN_WS_KC")
-    # ... and the 8-wave / 128-output-channel form of the lock-step kernel (LG_CNN_WIDE=1)
-    monkeypatch.setenv("LG_CNN_WIDE", "1")
-    for n in (41, 1, 2, 7):
-        np.testing.assert_array_equal(sel.cnn_forward(x[:n]).cpu().numpy(), default[:n], err_msg=f"wide kernel n {n}")
-    monkeypatch.delenv("LG_CNN_WIDE")
     sel.clear_cnn()
 
 
@@ -364,6 +374,77 @@ def test_select_grasp_point_vs_oracle(sel, shape, seed, with_cnn):
     sel.clear_cnn()
 
 
+def _largest_leaf(labels):
+    """The label with the largest area: the benchmark's notion of 'the chosen leaf' (a big interior leaf with >= 20
+    strictly positive candidates at full size), unlike label 1, which later ellipses may occlude."""
+    ids, counts = np.unique(labels[labels > 0], return_counts=True)
+    return int(ids[np.argmax(counts)])
+
+
+@pytest.mark.parametrize("seed", [22, 23, 21])
+def test_select_grasp_point_1080p_with_cnn_vs_oracle(sel, seed):
+    """BASELINE config 2 end to end at its full size (grasp_point_selector.py:184-253): 1080x1920, eight planes, top-20
+    candidates, GraspPointCNN rescoring, 3-D point and pre-grasp point against the float64 oracle."""
+    H, W = 1080, 1920
+    labels, depth, P = O.synthetic_scene(H, W, seed)
+    mask = (labels == _largest_leaf(labels)).astype(np.uint8)
+    sel.set_camera_params(P)
+    params = O.cnn_closed_form_params(seed=0)
+    sel.set_cnn_state_dict(params)
+    ref = _oracle(P, cnn=lambda x: O.cnn_forward(params, x))
+    exp, dbg = ref.select_grasp_point(mask, depth, return_debug=True)
+    assert len(dbg["candidates"]) == 20
+    tr = dbg["scores"]["traditional_score"]
+    if seed != 21:   # seed 21: the whole leaf lies under the stem penalty -> zero-score fall-through (the build's total order)
+        assert all(tr[y, x] > 0.5 for (x, y) in dbg["candidates"])
+    got = sel.select_grasp_point(torch.from_numpy(mask.astype(bool)).cuda(), torch.from_numpy(depth).cuda(), None)
+    assert got[0] == exp[0]                                        # 2-D point: integer, exact
+    np.testing.assert_allclose(got[1], exp[1], rtol=1e-5)
+    np.testing.assert_allclose(got[2], exp[2], rtol=1e-5)
+    maps, valid, _ = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda())
+    assert sel._get_candidate_points(maps["traditional_score"], valid, 20, 10) == dbg["candidates"]
+    for k, v in dbg["scores"].items():
+        np.testing.assert_allclose(maps[k].cpu().numpy(), v, rtol=RTOL, atol=ATOL, err_msg=k)
+    sel.clear_cnn()
+
+
+def test_config3_per_gpu_share_b32_1080p(sel):
+    """BASELINE config 3: 256 frames of 1080x1920 over 8 GPUs = 32 frames per GPU in one select_grasp_points_batch call.
+    Every frame of the batch equals its single-frame call; four distinct scenes equal the float64 oracle (CNN included)."""
+    H, W = 1080, 1920
+    seeds = [31, 32, 33, 34, 35, 36, 37, 38]
+    scenes = [O.synthetic_scene(H, W, s) for s in seeds]
+    P = scenes[0][2]
+    sel.set_camera_params(P)
+    params = O.cnn_closed_form_params(seed=0)
+    sel.set_cnn_state_dict(params)
+    base_m = [sc[0] == _largest_leaf(sc[0]) for sc in scenes]
+    order = [(i * 5 + 3) % 8 for i in range(32)]
+    masks = torch.from_numpy(np.stack([base_m[i] for i in order])).cuda()
+    depths = torch.from_numpy(np.stack([scenes[i][1] for i in order])).cuda()
+    batch = sel.select_grasp_points_batch(masks, depths)
+    assert len(batch) == 32
+    singles = {}
+    for j, i in enumerate(order):
+        if i not in singles:
+            singles[i] = sel.select_grasp_point(masks[j], depths[j], None)
+        assert batch[j] == singles[i], f"frame {j} (scene {i})"
+    ref = _oracle(P, cnn=lambda x: O.cnn_forward(params, x))
+    for i in (0, 3, 5, 6):
+        exp = ref.select_grasp_point(base_m[i].astype(np.uint8), scenes[i][1])
+        got = singles[i]
+        assert got[0] == exp[0], f"scene {i}"
+        np.testing.assert_allclose(got[1], exp[1], rtol=1e-5)
+        np.testing.assert_allclose(got[2], exp[2], rtol=1e-5)
+    sel.clear_cnn()
+
+
+def test_4k_all_planes_vs_oracle(sel):
+    """BASELINE config 4 (2160x3840): all eight planes + valid against the oracle (float planes 1e-4, integer work exact)."""
+    labels, depth, P = O.synthetic_scene(2160, 3840, 8)
+    _compare_maps(sel, (labels == _largest_leaf(labels)).astype(np.uint8), depth, P)
+
+
 def test_error_convention(L):
     s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
     m = torch.zeros((64, 64), dtype=torch.bool).cuda()
@@ -375,7 +456,7 @@ def test_error_convention(L):
 
 
 # ----------------------------------------------------------------------------- batches, pipeline variant, robustness
-def test_batched_select_equals_single_calls_1080p(sel):
+def test_batched_select_equals_single_calls_1080p(L, sel, monkeypatch):
     """BASELINE config 3 per-GPU share in miniature: a batch of 1080p frames gives exactly the per-frame results."""
     H, W = 1080, 1920
     frames = [O.synthetic_scene(H, W, 100 + s) for s in range(3)]
@@ -389,13 +470,13 @@ def test_batched_select_equals_single_calls_1080p(sel):
     singles = [sel.select_grasp_point(masks[i], depths[i], None) for i in range(3)]
     for j, i in enumerate(order):
         assert batch[j] == singles[i]
-    # the experimental sub-batch pipeline (multi-stream) must give identical results
-    import os
-    os.environ["LG_SUBBATCH"] = "3"
-    try:
-        assert sel.select_grasp_points_batch(masks, depths) == batch
-    finally:
-        del os.environ["LG_SUBBATCH"]
+    # the experimental sub-batch pipeline (multi-stream; switch read when the handle is created) must give identical results
+    monkeypatch.setenv("LG_SUBBATCH", "3")
+    piped = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    monkeypatch.delenv("LG_SUBBATCH")
+    piped.set_camera_params(P)
+    piped.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
+    assert piped.select_grasp_points_batch(masks, depths) == batch
     sel.clear_cnn()
 
 

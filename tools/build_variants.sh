@@ -10,7 +10,7 @@ for spec in "$@"; do
   name="${spec%%:*}"; extra="${spec#*:}"
   src="${LG_VARIANT_SRC:-lg_cnn.hip}"; obj="${src%.hip}.o"
   /opt/rocm/bin/hipcc $FLAGS $extra -c "$src" -o "variants/${name}_$obj" 2>/dev/null
-  objs=""; for o in lg_kernels.o lg_cnn.o lg_leaf.o lg_api.o lg_contour.o; do
+  objs=""; for o in $(make -s print-objs); do
     if [ "$o" = "$obj" ]; then objs="$objs variants/${name}_$obj"; else objs="$objs $o"; fi; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "variants/liblgrasp_${name}.so" $objs -lpthread
   echo "built variants/liblgrasp_${name}.so"
