@@ -33,21 +33,47 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 FINAL_BYTES_PER_PX = 4 + 4 + 0.125 + 0.125 + 28 + 1
 PATH_BYTES_PER_PX = 38.0  # whole-path compulsory traffic per pixel
 BASELINE_METRIC = "frames/sec (1080p depth+mask) grasp scoring, 1/8 MI355X; % HBM roofline"  # BASELINE.json:metric
-CPU_BASELINE_THREADS = 16  # one GPU's share of the box's host cores (torch intra-op threads of the CPU leg)
 
 
-def make_frames(B, H, W, n_distinct=4):
+def _cpu_share():
+    """Host cores this process may use (cgroup / affinity aware), capped at one GPU's share of an 8-GPU node's 256."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        n = os.cpu_count() or 1
+    return max(1, min(32, n))
+
+
+N_DISTINCT = 32  # distinct synthetic scenes in the benchmark batch (the batch cycles through them)
+
+
+def _scene(args):
     import synthetic_inputs as SI  # seeded scenes (inputs; the oracle is only touched by the cpu_baseline leg)
 
-    masks, depths, P = [], [], None
-    for s in range(min(B, n_distinct)):
-        labels, depth, P = SI.synthetic_scene(H, W, seed=100 + s)
-        masks.append(labels == 1)
-        depths.append(depth)
+    H, W, seed = args
+    labels, depth, P = SI.synthetic_scene(H, W, seed=seed)
+    ids, counts = np.unique(labels[labels > 0], return_counts=True)
+    chosen = int(ids[np.argmax(counts)])   # "binary optimal_mask = labels == chosen id" (SURVEY 8d): the largest leaf
+    return labels, depth, P, chosen
+
+
+def make_frames(B, H, W, n_distinct=N_DISTINCT, workers=1):
+    """-> masks [B,H,W] bool, depths [B,H,W] f32, P, labels of the distinct scenes [n,H,W] int16.  Must run before the
+    process touches the GPU when workers > 1 (fork)."""
+    jobs = [(H, W, 100 + s) for s in range(min(B, n_distinct))]
+    if workers > 1 and len(jobs) > 1:
+        from concurrent.futures import ProcessPoolExecutor
+
+        with ProcessPoolExecutor(max_workers=min(workers, len(jobs))) as ex:
+            res = list(ex.map(_scene, jobs))
+    else:
+        res = [_scene(j) for j in jobs]
+    masks = [r[0] == r[3] for r in res]
+    depths = [r[1] for r in res]
     reps = (B + len(masks) - 1) // len(masks)
     m = np.stack((masks * reps)[:B])
     d = np.stack((depths * reps)[:B])
-    return m, d, P
+    return m, d, res[0][2], np.stack([r[0] for r in res]).astype(np.int16)
 
 
 def final_kernel_bytes(masks_np, wins, H, W, tile_w=64, tile_h=16):
@@ -72,25 +98,36 @@ def final_kernel_bytes(masks_np, wins, H, W, tile_w=64, tile_h=16):
     return total
 
 
-def cpu_baseline(H, W, P, params, n_frames):
+def cpu_baseline(H, W, P, params, n_frames, threads):
     """Restated reference-equivalent CPU path (oracle, NumPy/torch-CPU + C chamfer): same work as
     scripts/utils/grasp_point_selector.py::select_grasp_point.  NOT the reference's own timing
-    (OpenCV / scikit-fmm are absent from this image)."""
+    (OpenCV / scikit-fmm are absent from this image).  Returns (per-frame seconds after one
+    warm-up frame, single-thread milliseconds of the serial C pieces)."""
     from oracle import lg_oracle as O
 
-    torch.set_num_threads(CPU_BASELINE_THREADS)
+    torch.set_num_threads(threads)
     ref = O.RefGraspPointSelector(cnn=lambda x: O.cnn_forward(params, x))
     ref.set_camera_params(P)
-    times = []
+    times, serial = [], {}
     for s in range(n_frames + 1):
-        labels, depth, _ = O.synthetic_scene(H, W, seed=100 + (s % 4))
-        mask = (labels == 1).astype(np.uint8)
+        labels, depth, _, chosen = _scene((H, W, 100 + (s % N_DISTINCT)))
+        mask = (labels == chosen).astype(np.uint8)
         t0 = time.perf_counter()
-        ref.select_grasp_point(mask, depth, tie_rule="numpy")
+        _, dbg = ref.select_grasp_point(mask, depth, tie_rule="numpy", return_debug=True)
         dt = time.perf_counter() - t0
         if s > 0:  # first frame is warm-up
             times.append(dt)
-    return times
+        if s == 1:   # BASELINE.md section 4 item 3: single-thread C / NumPy timing of the serial pieces, one frame
+            t0 = time.perf_counter()
+            O.distance_transform(mask, 5)
+            serial["chamfer_dt5_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            t0 = time.perf_counter()
+            ref._get_candidate_points(dbg["scores"]["traditional_score"], dbg["valid"], 20, 10, "numpy")
+            serial["argsort_nms_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            t0 = time.perf_counter()
+            O.leaf_orientation_raw(mask)
+            serial["contour_min_area_rect_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+    return times, serial
 
 
 def main():
@@ -102,7 +139,7 @@ def main():
                     help="frames per step per GPU (256 puts two sweep workgroups on every CU; 24 GB of the 288 GB)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames timed for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="frames timed for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cnn", action="store_true", help="CV-only (diagnostic; NOT the headline config)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU (each on its own handle, stream and host thread); >1 lets the "
@@ -113,6 +150,12 @@ def main():
     ap.add_argument("--train-steps", type=int, default=30,
                     help="N=1 only: optimisation steps of the GraspPointCNN training step (lg_train_step: forward + backward + "
                          "clip + Adam) timed at the reference's batch size 16 and at 1024, reported as `train_step` (0 = skip)")
+    ap.add_argument("--dense-steps", type=int, default=4,
+                    help="N=1 only: untimed passes of lg_final_kernel with EVERY tile on the stencil path (all-leaves masks, "
+                         "constant-tile fast path off), reported as `roofline_dense` (0 = skip)")
+    ap.add_argument("--h2d-steps", type=int, default=3,
+                    help="N=1 only: steps of pinned-host -> device copy of depth + mask followed by the scoring pass, reported "
+                         "as `h2d_inclusive` (never `value`; 0 = skip)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: print every step's wall time to stderr "
                                                             "(adds a device sync per step; not the headline mode)")
     args = ap.parse_args()
@@ -120,6 +163,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # synthetic frames first: the scene generator forks worker processes, which must happen before this process touches the GPU
+    H, W, B = args.height, args.width, args.batch
+    cpu_share = _cpu_share()
+    masks_np, depths_np, P, labels_np = make_frames(B, H, W, workers=max(1, min(8, cpu_share // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -142,8 +189,6 @@ def main():
     from leafgrasp_amd._lib import lib
     import synthetic_inputs as SI  # seeded scenes + closed-form CNN weights (inputs)
 
-    H, W, B = args.height, args.width, args.batch
-    masks_np, depths_np, P = make_frames(B, H, W)
     masks = torch.from_numpy(masks_np).to(dev)
     depths = torch.from_numpy(depths_np).to(dev)
     import threading
@@ -263,7 +308,7 @@ def main():
         if "final" in kern:
             # algorithmic bytes of THIS launch: tiles without a leaf pixel in stencil reach take the constant-store path
             # (no depth read); dense figure (every tile on the full path) = 37.25 B/px
-            n_distinct = min(B, 4)
+            n_distinct = min(B, N_DISTINCT)
             wins = [sels[0].dt_maxima(i)[2] for i in range(n_distinct)]
             per_distinct = [final_kernel_bytes(masks_np[i:i + 1], wins[i:i + 1], H, W) for i in range(n_distinct)]
             launch_bytes = sum(per_distinct[i % n_distinct] for i in range(B))
@@ -279,7 +324,8 @@ def main():
             out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "bytes_per_launch": round(launch_bytes),
-                               "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX}
+                               "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX,
+                               "distinct_scenes": n_distinct}
         if "cnn" in kern and not args.no_cnn:
             # MFMA flops actually executed per 9x32x32 patch: layer 0 direct (K = 9 taps x 10 padded channels),
             # layers 1..5 Winograd F(2x2,3x3) = 16 positions x 2 x Cout x Cin x tiles (2.25x fewer than direct).
@@ -295,22 +341,102 @@ def main():
                            "executed_mflop_per_patch": round(exec_fl / 1e6, 2),
                            "direct_equivalent": round(312.83e6 * 20 * B / sec / 1e12, 2)}
         if world == 1 and args.cpu_frames > 0:
-            times = cpu_baseline(H, W, P, params, args.cpu_frames)
+            times, serial = cpu_baseline(H, W, P, params, args.cpu_frames, cpu_share)
             out["cpu_baseline"] = {
                 "value": round(len(times) / sum(times), 4), "unit": "frames/s",
-                "cores": CPU_BASELINE_THREADS, "kind": "port",
-                "sample": f"{len(times)} synthetic {H}x{W} frames through oracle/lg_oracle.py "
-                          f"(restated NumPy/torch-CPU + C chamfer path, numpy argsort, 20 batch-1 CNN forwards; "
-                          f"NumPy planes single-threaded, torch CPU ops on {CPU_BASELINE_THREADS} threads); "
-                          f"os.cpu_count()={os.cpu_count()}"}
+                "cores": cpu_share, "kind": "port",
+                "median_s_per_frame": round(float(np.median(times)), 4), "min_s_per_frame": round(float(np.min(times)), 4),
+                "torch_threads": torch.get_num_threads(), "os_cpu_count": os.cpu_count(),
+                "c_single_thread_ms": serial,
+                "sample": f"{len(times)} synthetic {H}x{W} frames (after 1 warm-up) through oracle/lg_oracle.py: the restated "
+                          f"reference-equivalent CPU path (NumPy float64 planes + C chamfer / contour code single-threaded, "
+                          f"numpy argsort, 20 batch-1 torch-CPU CNN forwards on {cpu_share} threads); OpenCV / scikit-fmm "
+                          f"replaced by in-repo equivalents -- not the reference's own timing"}
+        if world == 1 and args.dense_steps > 0:
+            # secondary roofline (never `value`): the STENCIL path of lg_final_kernel on every tile.  The headline launch is
+            # ~96 % constant-store tiles (a leaf covers a few per cent of a frame); here the masks are "every leaf" (labels >= 1)
+            # and the handle is created with the constant-tile fast path off (LG_NO_SKIP, read at lg_create), so each tile
+            # reads depth (+ distance inside the sweep window, or writes it outside), runs the 5x5 Gaussian + 3x3 Sobel through
+            # LDS and writes 7 planes + valid: 37.25 B/px for every pixel of the launch.
+            try:
+                os.environ["LG_NO_SKIP"] = "1"
+                dsel = L.GraspPointSelector(dev, load_model=False)
+                del os.environ["LG_NO_SKIP"]
+                dsel.set_camera_params(P)
+                nd = min(B, 128)
+                dm = torch.from_numpy(np.stack([labels_np[i % len(labels_np)] >= 1 for i in range(nd)]).astype(np.uint8)).to(dev)
+                dd = depths[:nd]
+                dsel.score_maps(dm, dd)
+                lib.lg_profile_enable(dsel._h, 2)
+                for _ in range(args.dense_steps):
+                    dsel.score_maps(dm, dd)
+                torch.cuda.synchronize(dev)
+                n_l, ms_l = C.c_int(0), C.c_double(0.0)
+                lib.lg_profile_read(dsel._h, b"final", C.byref(n_l), C.byref(ms_l))
+                lib.lg_profile_enable(dsel._h, 0)
+                dbytes = FINAL_BYTES_PER_PX * nd * H * W
+                dach = dbytes / (ms_l.value / max(1, n_l.value) * 1e-3) / 1e9
+                traffic_d = None
+                try:
+                    with open(os.path.join(REPO, "profiles", "r02_pmc_final_dense.json")) as fpmc:
+                        traffic_d = round(json.load(fpmc)["traffic_bytes_per_px"] * nd * H * W)
+                except Exception:  # noqa: BLE001
+                    traffic_d = None
+                out["roofline_dense"] = {"kernel": "lg_final_kernel (every tile on the stencil path)", "bound": "hbm",
+                                         "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": traffic_d,
+                                         "bytes_per_px": FINAL_BYTES_PER_PX, "frames_per_launch": nd, "launches": n_l.value,
+                                         "avg_ms": round(ms_l.value / max(1, n_l.value), 4),
+                                         "masks": "labels >= 1 (all leaves, 20-30 % of the frame), LG_NO_SKIP=1"}
+                dsel = dm = dd = None
+            except Exception as e:  # noqa: BLE001
+                out["roofline_dense"] = {"error": str(e)}
+        if world == 1 and args.h2d_steps > 0 and not args.no_cnn:
+            # secondary figure (never `value`, SURVEY 8d "Timing method"): the same scoring pass with depth f32 + mask u8 arriving
+            # from PINNED host memory every step (10.4 MB per 1080p frame over PCIe Gen5)
+            try:
+                nh = min(B, 64)
+                hm = masks_np[:nh].view(np.uint8)
+                h_mask = torch.from_numpy(hm).pin_memory()
+                h_depth = torch.from_numpy(depths_np[:nh]).pin_memory()
+                d_mask = torch.empty_like(h_mask, device=dev)
+                d_depth = torch.empty_like(h_depth, device=dev)
+
+                def h2d_step():
+                    d_mask.copy_(h_mask, non_blocking=True)
+                    d_depth.copy_(h_depth, non_blocking=True)
+                    return sels[0].select_grasp_points_batch(d_mask.view(torch.bool), d_depth)
+                h2d_step()
+                torch.cuda.synchronize(dev)
+                t_h = time.perf_counter()
+                for _ in range(args.h2d_steps):
+                    r_h = h2d_step()
+                torch.cuda.synchronize(dev)
+                dt_h = time.perf_counter() - t_h
+                torch.cuda.synchronize(dev)
+                t_c = time.perf_counter()
+                for _ in range(args.h2d_steps):
+                    d_mask.copy_(h_mask, non_blocking=True)
+                    d_depth.copy_(h_depth, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                dt_c = time.perf_counter() - t_c
+                out["h2d_inclusive"] = {"value": round(nh * args.h2d_steps / dt_h, 1), "unit": "frames/s",
+                                        "frames_per_step": nh, "steps": args.h2d_steps,
+                                        "copy_only_GBps": round(nh * H * W * 5 * args.h2d_steps / dt_c / 1e9, 2),
+                                        "what": "pinned host depth f32 + mask u8 -> device (one stream), then the scoring pass "
+                                                "incl. CNN; copy and compute not overlapped"}
+                assert all(r[0] is not None for r in r_h)
+                h_mask = h_depth = d_mask = d_depth = None
+            except Exception as e:  # noqa: BLE001
+                out["h2d_inclusive"] = {"error": str(e)}
         if world == 1 and args.node_steps > 0 and not args.no_cnn:
             # secondary figure (never `value`): the node's whole per-frame sequence, leaf_grasp_node_v3.py:102-158 --
             # OptimalLeafSelector over the int16 label image, then GraspPointSelector on the chosen leaf -- batched
             try:
                 nb = min(B, 128)
-                scenes = [SI.synthetic_scene(H, W, seed=100 + s) for s in range(min(nb, 4))]
-                lab = torch.from_numpy(np.stack([scenes[i % len(scenes)][0] for i in range(nb)]).astype(np.int16)).to(dev)
-                dep = torch.from_numpy(np.stack([scenes[i % len(scenes)][1] for i in range(nb)])).to(dev)
+                nsc = len(labels_np)
+                lab = torch.from_numpy(np.stack([labels_np[i % nsc] for i in range(nb)])).to(dev)
+                dep = depths[:nb] if nb <= B and B % nsc == 0 else torch.from_numpy(np.stack([depths_np[i % nsc] for i in range(nb)])).to(dev)
                 hz = L.LeafGraspHarness(H, W, dev, load_model=False)
                 hz.camera_info_callback(np.asarray(P).reshape(-1))
                 hz.grasp_selector.set_cnn_state_dict(params)

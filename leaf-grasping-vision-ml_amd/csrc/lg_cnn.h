@@ -20,6 +20,8 @@ struct LgCnn {
     float* wconv[8] = {nullptr};  // packed [ky][kx][cin_pad][cout], BN folded (layer 0; all layers of the standard model)
     float* bconv[8] = {nullptr};
     float* uwino[8] = {nullptr};  // Winograd F(2x2,3x3) weights [cin][cout][16] (layers 1..)
+    float* uwino4[8] = {nullptr}; // Winograd F(4x4,3x3) weights in lg_wino4_kernel's fragment order (layers 1..)
+    bool use_f23 = false;         // LG_CNN_F23 at load time: F(2x2,3x3) kernels instead of F(4x4,3x3)
     float* att_w = nullptr;       // [256] spatial attention (1x1 conv 256 -> 1)
     float att_b = 0.f;
     int att_type = 0;             // LG_ATT_*

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restric
 // 16w..16w+15: M = 16 channels, N = 16 tiles, K = 4 input channels per MFMA, 16 positions x 2 tile halves = 32
 // accumulators (128 VGPRs); every lane ends with all 16 positions of its (channel, tile) pairs: the output transform +
 // bias + ReLU (+ the 2x2 max-pool = one output tile) needs no exchange.
-//   * A operand  U[ci][co][16]: 64 contiguous bytes per lane from L2 into registers, next k-step prefetched.
+//   * A operand  U: four 1 KiB-contiguous wave loads per k-step from L2 into registers, next k-step prefetched.
 //   * B operand  V[ci][tile][16 (+4 pad)]: the band's haloed rows of a chunk of 8 channels stream into a 2-stage LDS ring
 //     as 16-byte DMA pieces (2-3 per thread and chunk), are transformed by thread (ci, tile) = (t>>5, t&31) and read
 //     back as 4 ds_read_b128 per tile half (row stride 80 B: conflict free).
@@ -380,12 +380,16 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < NIN; j++) LG_DMA16(in_c + voff[j], sb + 4 * (THREADS * j + 64 * wave));
     };
-    // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co]
-    const float* u_lane = U + ((size_t)(lane >> 4) * COUT + co0 + 16 * wave + (lane & 15)) * 16;
+    // ---- A operand: lane (co = lane & 15, k = lane >> 4) reads the 16 positions of U[ci][co], stored
+    //      [k-step][16-channel block][position group q][lane][4 positions]: every wave instruction reads 1 KiB of CONSECUTIVE
+    //      bytes (16 cache lines).  The first layout, [ci][co][16], had each lane read its own 64-byte row: 64 lines per
+    //      instruction, and the vector L1 looks up one line per clock -- 8 such loads per wave and chunk kept it busy for
+    //      the whole chunk (0.60 of the MFMA peak with everything else in place).
+    const float* u_lane = U + ((size_t)(co0 / 16 + wave) * 256 + lane) * 4;
     auto load_u = [&](int ks, f32x4 (&a)[4]) {             // ks = global k-step (4 input channels each)
-        const f32x4* p = reinterpret_cast<const f32x4*>(u_lane + (size_t)ks * 4 * COUT * 16);
+        const float* p = u_lane + (size_t)ks * (COUT / 16) * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; q++) a[q] = p[q];
+        for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const f32x4*>(p + 256 * q);
     };
     // ---- transform role: (channel of the chunk, tile)
     const int tci = t >> 5, tau = t & 31;
@@ -501,6 +505,259 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
                     float* o0 = o + (2 * trg) * OP + 2 * tcg;    // (interior pixels start at an odd column: dword stores)
                     o0[0] = fmaxf(y00, 0.f); o0[1] = fmaxf(y01, 0.f);
                     o0[OP] = fmaxf(y10, 0.f); o0[OP + 1] = fmaxf(y11, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(4x4,3x3):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 6x6 input tile d / 4x4 output tile Y: 36 independent
+// contractions over the input channels, 4x fewer MFMA flops than the direct form (F(2x2,3x3): 2.25x).  Products and
+// accumulation stay exact f32 (v_mfma_f32_16x16x4_f32); the transforms' small integer / dyadic coefficients cost ~1e-6 of
+// relative error on the logits (tests compare with the reference's fp64 logits at 1e-4; the F(2x2,3x3) and direct kernels
+// remain selectable as second opinions: LG_CNN_F23=1, LG_CNN_DIRECT=1).
+//
+// Workgroup = 512 threads = 8 waves = 64 output channels x 32 tiles x all 36 positions; chunks of 4 input channels
+// (one MFMA k-step).  Wave w owns channel block cb = w & 3 (16 channels) and tile block tb = w >> 2 (16 tiles): 36
+// accumulators (144 VGPRs); a lane ends with all 36 positions of its 4 (channel, tile) pairs, so the output transform,
+// bias, ReLU and the 2x2 max-pool need no exchange.
+//   * A operand: the chunk's 36 KB block of U -- stored in global memory in exactly the order the fragments are read,
+//     [k-step][64-channel block][cb][position group of 4][lane = (k, channel)][4 positions] -- streams into a 2-stage LDS ring
+//     by 16-byte DMA (4.5 transfers per thread and chunk) and is shared by the two tile-block waves of a channel block:
+//     one ds_read_b128 per 4 MFMAs.
+//   * B operand: the band's haloed input rows of the chunk's 4 channels arrive by 16-byte DMA (2-3 transfers per thread),
+//     are transformed (V = B^T d B, work item = (channel, tile, row of V): 768 items per chunk on 512 threads) into
+//     V[tb][position group][lane = (k, tile)][4 positions] -- again one ds_read_b128 per 4 MFMAs, shared by 4 waves.
+//   The transform of chunk c + 1 is issued between the MFMAs of chunk c (its LDS reads first, so their latency hides
+//   behind matrix work; its VALU adds to the MFMA time -- f32 MFMA and VALU share the FMA lanes); ONE barrier per chunk.
+template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR>
+__global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__ in, const float* __restrict__ U4,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int N, int ntb) {
+    constexpr int THREADS = 512;
+    constexpr int KC = 4;
+    constexpr int TC = WI / 4, TP = TC * TC;               // tile columns, tiles per patch
+    constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup
+    constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // workgroups (row bands) per patch
+    constexpr int TPB = 32 / PB;                           // tiles of one patch inside the workgroup
+    constexpr int TROWS = TPB / TC;                        // tile rows per band
+    constexpr int WP = lg_wp(WI), PLANE = lg_plane(WI);
+    constexpr int RH = 4 * TROWS + 2;                      // staged haloed rows per channel and patch
+    constexpr int RS = RH * WP, S = PB * RS;
+    constexpr int PPC = RS / 4;
+    constexpr int NPIECE = KC * PB * PPC;
+    constexpr int NIN = (NPIECE + THREADS - 1) / THREADS;
+    constexpr int STAGE = NIN * THREADS * 4;               // floats per input stage
+    constexpr int ABLK = 64 * 36 * KC;                     // 9216 floats of U per (k-step, 64-channel block)
+    constexpr int VBLK = 32 * 36 * KC;                     // 4608 floats of V per chunk
+    constexpr int NCB = COUT / 64;
+    constexpr int NC = CIN / KC;
+    static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (RS % 4) == 0 && TROWS >= 1, "shape");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * ABLK + 2 * VBLK + 2 * STAGE];
+    float* const s_a = s_mem;
+    float* const s_v = s_mem + 2 * ABLK;
+    float* const s_in = s_mem + 2 * ABLK + 2 * VBLK;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // XCD-aware order (workgroups b, b + 8, ... share an XCD and its L2; an XCD starts them in the order of b / 8).  XCD x owns
+    // the tile blocks tb = 8 * local + x and all NCB channel blocks of them.  Small U (fits L2 beside the inputs): channel
+    // block fastest, the NCB readers of an input band run back to back.  Large U (layers 4-5: 4.7 / 9.4 MB against 4 MB of
+    // L2): channel block slowest, every CU of the XCD streams the SAME 64-channel slice of U while the XCD's input bands
+    // stream past once per slice.  The grid is 8 * ceil(ntb / 8) * NCB; workgroups past the last tile block leave at once.
+    const int ntbx = (ntb + 7) / 8;
+    const int xcd = blockIdx.x % 8, jx = blockIdx.x / 8;
+    const int cob = COB_MAJOR ? jx / ntbx : jx % NCB;
+    const int tbk = (COB_MAJOR ? jx % ntbx : jx / NCB) * 8 + xcd;
+    if (tbk >= ntb) return;
+    const int n0 = PB > 1 ? tbk * PB : tbk / BPP;
+    const int band = PB > 1 ? 0 : tbk % BPP;
+    const int y0 = band * 4 * TROWS;                       // first staged haloed row (= output row y0 - 1)
+    const int co0 = cob * 64;
+
+    // ---- staging offsets
+    const float* in_n = in + (size_t)n0 * CIN * PLANE;
+    unsigned voff[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int e = t + THREADS * j;
+        const int ci = e / (PB * PPC), r = e % (PB * PPC);
+        const int pb = r / PPC, piece = r % PPC;
+        const bool ok = e < NPIECE && n0 + pb < N;
+        voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
+    }
+    auto issue_input = [&](int c, int stage) {
+        const char* in_c = (const char*)(in_n + (size_t)c * KC * PLANE);
+        float* sb = s_in + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < NIN; j++) LG_DMA16(in_c + voff[j], sb + 4 * (THREADS * j + 64 * wave));
+    };
+    const float* u_blk = U4 + (size_t)cob * ABLK + 4 * t;   // + c * NCB * ABLK per chunk, + 2048 floats per transfer
+    auto issue_a = [&](int c, int stage) {
+        const float* src = u_blk + (size_t)c * NCB * ABLK;
+        float* sb = s_a + stage * ABLK;
+#pragma unroll
+        for (int j = 0; j < 4; j++) LG_DMA16(src + 2048 * j, sb + 4 * (THREADS * j + 64 * wave));
+        if (wave < 4) LG_DMA16(src + 2048 * 4, sb + 4 * (THREADS * 4 + 64 * wave));   // 2304 pieces = 4.5 x 512
+    };
+
+    // ---- transform items: (row i of V, channel k, tile tau); item = i * 128 + k * 32 + tau: thread t takes item t and threads
+    //      0..255 item 512 + t, so a wave's 64 items share i (wave-uniform: scalar selects, no divergence).
+    //      r[j] = sum_q coef[i][q] * d[rowsel[i][q]][j]  (row i of B^T d), then the same 1-D transform along j
+    const int i_a = wave >> 1, i_b = 4 + (wave >> 1);        // row of V of this wave's first / second item (SGPRs)
+    const int tk = ((wave & 1) << 1) | (lane >> 5), tau = lane & 31;
+    const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WP + 4 * ((tau % TPB) % TC);
+    const int tdst = (((tau >> 4) * 9) * 64 + (tk * 16 + (tau & 15))) * 4;
+    auto transform_load = [&](int i, int stage, f32x4 (&dl)[4], f32x2 (&dh)[4]) {
+        const float* sp = s_in + stage * STAGE + tsrc;
+        // rows of d entering row i of B^T d: i = 0: 0,2,4,(4)  i = 1..4: 1,2,3,4  i = 5: 1,3,5,(5)
+        const int rr[4] = {i == 0 ? 0 : 1, i == 0 ? 2 : (i == 5 ? 3 : 2), i == 0 ? 4 : (i == 5 ? 5 : 3), i == 0 ? 4 : (i == 5 ? 5 : 4)};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float* p = sp + rr[q] * WP;                 // 16-byte aligned: tile columns start at multiples of 4 floats
+            dl[q] = *reinterpret_cast<const f32x4*>(p);
+            dh[q] = *reinterpret_cast<const f32x2*>(p + 4);
+        }
+    };
+    auto transform_store = [&](int i, int vstage, const f32x4 (&dl)[4], const f32x2 (&dh)[4]) {
+        // coefficients of the four rows (wave-uniform)
+        const float c0 = i == 0 ? 4.f : i == 1 ? -4.f : i == 2 ? 4.f : i == 3 ? -2.f : i == 4 ? 2.f : 4.f;
+        const float c1 = i == 0 ? -5.f : i == 1 ? -4.f : i == 2 ? -4.f : i == 3 ? -1.f : i == 4 ? -1.f : -5.f;
+        const float c2 = i == 0 ? 1.f : i == 1 ? 1.f : i == 2 ? -1.f : i == 3 ? 2.f : i == 4 ? -2.f : 1.f;
+        const float c3 = (i == 0 || i == 5) ? 0.f : 1.f;
+        float r[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const float d0 = j < 4 ? dl[0][j & 3] : dh[0][j & 1], d1 = j < 4 ? dl[1][j & 3] : dh[1][j & 1],
+                        d2 = j < 4 ? dl[2][j & 3] : dh[2][j & 1], d3 = j < 4 ? dl[3][j & 3] : dh[3][j & 1];
+            r[j] = fmaf(c0, d0, fmaf(c1, d1, fmaf(c2, d2, c3 * d3)));
+        }
+        float v[6];
+        v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+        const float a = fmaf(-4.f, r[2], r[4]), b = fmaf(-4.f, r[1], r[3]);
+        v[1] = a + b; v[2] = a - b;
+        const float cc = r[4] - r[2], e = 2.f * (r[3] - r[1]);
+        v[3] = cc + e; v[4] = cc - e;
+        v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
+        // positions 6i .. 6i+5 of lane (k, tau & 15) in tile block tau >> 4; i even: 6i % 4 == 0, i odd: 6i % 4 == 2
+        float* g0 = s_v + vstage * VBLK + tdst + ((6 * i) >> 2) * 256;
+        if ((i & 1) == 0) {
+            *reinterpret_cast<f32x4*>(g0) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x2*>(g0 + 256) = (f32x2){v[4], v[5]};
+        } else {
+            *reinterpret_cast<f32x2*>(g0 + 2) = (f32x2){v[0], v[1]};
+            *reinterpret_cast<f32x4*>(g0 + 256) = (f32x4){v[2], v[3], v[4], v[5]};
+        }
+    };
+
+    const int cb = wave & 3, tbw = wave >> 2;
+    const float* const a_rd = s_a + ((cb * 9) * 64 + lane) * 4;
+    const float* const b_rd = s_v + ((tbw * 9) * 64 + lane) * 4;
+    f32x4 acc[36];
+#pragma unroll
+    for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mfma_groups = [&](int stage, int pg0, int pg1) {
+#pragma unroll
+        for (int pg = pg0; pg < pg1; pg++) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(a_rd + stage * ABLK + pg * 256);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(b_rd + stage * VBLK + pg * 256);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[4 * pg + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[4 * pg + e], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
+    issue_input(0, 0);
+    issue_a(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        f32x4 dl[4];
+        f32x2 dh[4];
+        transform_load(i_a, 0, dl, dh);
+        transform_store(i_a, 0, dl, dh);
+        if (wave < 4) {
+            transform_load(i_b, 0, dl, dh);
+            transform_store(i_b, 0, dl, dh);
+        }
+    }
+    if (NC > 1) issue_input(1, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#pragma unroll 1
+    for (int c = 0; c < NC; c++) {
+        const int st = c & 1;
+        const bool more = c + 1 < NC;
+        if (more) issue_a(c + 1, st ^ 1);
+        if (c + 2 < NC) issue_input(c + 2, st);            // stage st: read by the transform of chunk c, one iteration ago
+        f32x4 dl[4];
+        f32x2 dh[4];
+        if (more) transform_load(i_a, st ^ 1, dl, dh);     // LDS reads first: their latency hides behind the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_groups(st, 0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) transform_store(i_a, st ^ 1, dl, dh);
+        if (more && wave < 4) transform_load(i_b, st ^ 1, dl, dh);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_groups(st, 3, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && wave < 4) transform_store(i_b, st ^ 1, dl, dh);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_groups(st, 6, 9);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
+    constexpr int WO = POOL ? WI / 2 : WI;
+    constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
+    constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
+    constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
+    const int etau = 16 * tbw + (lane & 15);
+    const int epb = etau / TPB, etl = etau % TPB;
+    const int n = n0 + epb;
+    const int trg = band * TROWS + etl / TC, tcg = etl % TC;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int co = co0 + 16 * cb + 4 * (lane >> 4) + r;
+        // stage 1 over the rows i of M (for every column j): s[p][j] = sum_i AT[p][i] m[i][j]
+        float s[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r],
+                        m5 = acc[30 + j][r];
+            const float t1 = m1 + m2, t2 = m1 - m2, t3 = m3 + m4, t4 = m3 - m4;
+            s[0][j] = m0 + t1 + t3;
+            s[1][j] = fmaf(2.f, t4, t2);
+            s[2][j] = fmaf(4.f, t3, t1);
+            s[3][j] = fmaf(8.f, t4, t2) + m5;
+        }
+        const float bv = bias[co];
+        float y[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
+            y[p][0] = s[p][0] + t1 + t3 + bv;
+            y[p][1] = fmaf(2.f, t4, t2) + bv;
+            y[p][2] = fmaf(4.f, t3, t1) + bv;
+            y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
+        }
+        if (n < N) {
+            float* o = out + ((size_t)n * COUT + co) * OPL + OO;
+            if (POOL) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
+                    const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
+                    float* o0 = o + (2 * trg + p) * OP + 2 * tcg;
+                    o0[0] = v0; o0[1] = v1;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    float* o0 = o + (4 * trg + p) * OP + 4 * tcg;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) o0[q] = fmaxf(y[p][q], 0.f);
                 }
             }
         }
@@ -667,11 +924,30 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const f
     return false;
 }
 
+bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
+                     float* out, int N, hipStream_t s) {
+    const int tp = (wi / 4) * (wi / 4);
+    const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
+    const int grid = 8 * ((ntb + 7) / 8) * (cout / 64);
+#define X(CI, CO, W_, P)                                                                                              \
+    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
+        constexpr bool CM = 36LL * CI * CO * 4 > 3 * 1024 * 1024;                                                     \
+        if (out_halo)                                                                                                 \
+            hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P, true, CM>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P, false, CM>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb); \
+        return true;                                                                                                  \
+    }
+    LG_WINO_SHAPES(X)
+#undef X
+    return false;
+}
+
 }  // namespace
 
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
-    for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); F(c->act[i]); }
+    for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); F(c->uwino4[i]); F(c->act[i]); }
     F(c->att_w); F(c->ca_w1); F(c->ca_b1); F(c->ca_w2); F(c->ca_b2);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
     F(c->in_halo); F(c->zeros);
@@ -746,7 +1022,8 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
             if (rc) return rc;
         }
         if (L >= 1) {
-            // Winograd-domain weights U = G g G^T of the BN-folded kernel, layout [ci][co][4i+j], rounded once from double
+            // Winograd-domain weights U = G g G^T of the BN-folded kernel (position 4i+j), rounded once from double, in the order
+            // lg_wino_kernel's A fragments are read
             std::vector<float> uw((size_t)l.cinp * l.coutp * 16, 0.0f);
             for (int co = 0; co < l.cout; co++) {
                 for (int ci = 0; ci < l.cin; ci++) {
@@ -759,16 +1036,41 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
                         gg[2][j] = 0.5 * (g[0][j] - g[1][j] + g[2][j]);
                         gg[3][j] = g[2][j];
                     }
-                    float* u = &uw[((size_t)ci * l.coutp + co) * 16];
+                    // [k-step = ci/4][16-channel block][q = position group][lane = (ci%4)*16 + co%16][4 positions]
+                    float* u = &uw[((((size_t)(ci / 4) * (l.coutp / 16) + co / 16) * 4) * 64 + (ci % 4) * 16 + co % 16) * 4];
                     for (int i = 0; i < 4; i++) {
-                        u[4 * i + 0] = (float)gg[i][0];
-                        u[4 * i + 1] = (float)(0.5 * (gg[i][0] + gg[i][1] + gg[i][2]));
-                        u[4 * i + 2] = (float)(0.5 * (gg[i][0] - gg[i][1] + gg[i][2]));
-                        u[4 * i + 3] = (float)gg[i][2];
+                        u[256 * i + 0] = (float)gg[i][0];
+                        u[256 * i + 1] = (float)(0.5 * (gg[i][0] + gg[i][1] + gg[i][2]));
+                        u[256 * i + 2] = (float)(0.5 * (gg[i][0] - gg[i][1] + gg[i][2]));
+                        u[256 * i + 3] = (float)gg[i][2];
                     }
                 }
             }
             rc = upload(&c->uwino[L], uw, err);
+            if (rc) return rc;
+            // F(4x4,3x3) weights U = G g G^T (6x6) of the BN-folded kernel in the order lg_wino4_kernel's A fragments are read:
+            // [k-step = ci/4][64-channel block][cb = (co%64)/16][position group pg = pos/4][lane = (ci%4)*16 + co%16][pos%4]
+            static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            std::vector<float> u4((size_t)l.cinp * l.coutp * 36, 0.0f);
+            const int ncb = l.coutp / 64;
+            for (int co = 0; co < l.cout; co++) {
+                for (int ci = 0; ci < l.cin; ci++) {
+                    double g[3][3], gg[6][3];
+                    for (int tap = 0; tap < 9; tap++)
+                        g[tap / 3][tap % 3] = (double)w->conv_w[L][((size_t)co * l.cin + ci) * 9 + tap] * scv[co];
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 3; j++) gg[i][j] = G4[i][0] * g[0][j] + G4[i][1] * g[1][j] + G4[i][2] * g[2][j];
+                    const size_t base = ((((size_t)(ci / 4) * ncb + co / 64) * 4 + (co % 64) / 16) * 9) * 256 + ((ci % 4) * 16 + co % 16) * 4;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 6; j++) {
+                            const int pos = 6 * i + j;
+                            u4[base + (size_t)(pos / 4) * 256 + pos % 4] =
+                                (float)(gg[i][0] * G4[j][0] + gg[i][1] * G4[j][1] + gg[i][2] * G4[j][2]);
+                        }
+                }
+            }
+            rc = upload(&c->uwino4[L], u4, err);
             if (rc) return rc;
         }
     }
@@ -820,6 +1122,8 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
     }
     // A/B and test switches of the standard encoder, read when the model is loaded (not on the per-call path):
     // LG_CNN_DIRECT=1 direct implicit GEMM for every layer; LG_CNN_WINO_MASK=<bits> bit L = layer L on Winograd
+    // LG_CNN_F23=1 the F(2x2,3x3) Winograd kernels instead of F(4x4,3x3)
+    c->use_f23 = getenv("LG_CNN_F23") != nullptr;
     c->wino_mask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
     if (const char* e = getenv("LG_CNN_WINO_MASK")) c->wino_mask = atoi(e) & 0x3e;
     c->loaded = true;
@@ -888,7 +1192,8 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
     do {                                                                                                            \
         const RtLayer& l = c->layers[L];                                                                            \
         if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, c->act[L], N, s);                               \
-        else launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
+        else if (c->use_f23) launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
+        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, s); \
         cur = c->act[L];                                                                                            \
     } while (0)
         LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
@@ -900,7 +1205,9 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
     } else {
         for (int L = 1; L < c->n_layers; L++) {
             const RtLayer& l = c->layers[L];
-            if (!launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)) {
+            const bool okl = c->use_f23 ? launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)
+                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, s);
+            if (!okl) {
                 *err = "lg_cnn_forward: unsupported layer shape";
                 return LG_ERR_UNSUPPORTED;
             }
