@@ -327,17 +327,25 @@ def main():
                                "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX,
                                "distinct_scenes": n_distinct}
         if "cnn" in kern and not args.no_cnn:
-            # MFMA flops actually executed per 9x32x32 patch: layer 0 direct (K = 9 taps x 10 padded channels),
-            # layers 1..5 Winograd F(2x2,3x3) = 16 positions x 2 x Cout x Cin x tiles (2.25x fewer than direct).
-            # `direct_equivalent` prices the same launches with the reference network's 312.83 MFLOP / patch.
+            # MFMA flops actually executed per 9x32x32 patch (2 x MACs): Winograd F(4x4,3x3) = 36 positions x Cout x Cin x
+            # tiles (4x fewer than direct), layer 0 on 12 padded input planes; F(2x2,3x3) = 16 positions (2.25x fewer) with
+            # layer 0 direct on 10 padded planes; direct = the reference network's 312.83 MFLOP / patch.
+            # `direct_equivalent` prices the same launches with that 312.83 MFLOP.
             direct = os.environ.get("LG_CNN_DIRECT") is not None
-            exec_fl = 312.83e6 if direct else (2 * 64 * 90 * 1024 + 16 * 2 * (64 * 64 * 256 + 128 * 64 * 64 + 128 * 128 * 64
-                                                                             + 256 * 128 * 16 + 256 * 256 * 16))
+            f23 = os.environ.get("LG_CNN_F23") is not None
+            wino_macs = lambda pos, tiles: pos * (64 * 64 * tiles[0] + 128 * 64 * tiles[1] + 128 * 128 * tiles[1]  # noqa: E731
+                                                  + 256 * 128 * tiles[2] + 256 * 256 * tiles[2])
+            if direct:
+                exec_fl, kname = 312.83e6, "lg_conv0_kernel + lg_conv3x3_kernel x5 (direct implicit GEMM) + head"
+            elif f23:
+                exec_fl = 2 * (64 * 90 * 1024 + wino_macs(16, (256, 64, 16)))
+                kname = "lg_conv0_kernel (layer 0 direct) + lg_wino_kernel x5 (Winograd F(2x2,3x3)) + head"
+            else:
+                exec_fl = 2 * (36 * 64 * 12 * 64 + wino_macs(36, (64, 16, 4)))
+                kname = "lg_wino4_kernel x6 (Winograd F(4x4,3x3), layer 0 on 12 padded planes) + head"
             sec = kern["cnn"]["avg_ms"] * 1e-3
             tf = exec_fl * 20 * B / sec / 1e12
-            out["mfma"] = {"kernel": "lg_conv0_kernel (layer 0) + lg_wino_kernel x5 (Winograd F(2x2,3x3)) + head"
-                                     if not direct else "lg_conv3x3_kernel x6 + head",
-                           "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+            out["mfma"] = {"kernel": kname, "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                            "executed_mflop_per_patch": round(exec_fl / 1e6, 2),
                            "direct_equivalent": round(312.83e6 * 20 * B / sec / 1e12, 2)}
         if world == 1 and args.cpu_frames > 0:

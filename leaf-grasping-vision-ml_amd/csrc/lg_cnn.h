@@ -33,15 +33,15 @@ struct LgCnn {
     float* fcb[4] = {nullptr};
     float* act[8] = {nullptr};    // output of layer L for capN patches: haloed planes [coutp][(wo+2)][(wo+4)] (lg_cnn.hip), the
     size_t act_per[8] = {0};      //   last layer dense [coutp][wo*wo] for the head; one buffer per layer: halos stay zero
-    float* in_halo = nullptr;     // haloed copy [capN][9][34][36] of dense input patches (lg_cnn_forward through the C-ABI)
+    float* in_halo = nullptr;     // haloed copy [capN][12][34][36] (9 feature planes + 3 zero planes) of dense input patches (lg_cnn_forward through the C-ABI)
     float* zeros = nullptr;       // 4096 zero floats
-    int wino_mask = 0x3e;         // standard encoder: bit L = layer L on Winograd (LG_CNN_DIRECT / LG_CNN_WINO_MASK at load time)
+    int wino_mask = 0x3f;         // bit L = layer L on Winograd (LG_CNN_DIRECT / LG_CNN_WINO_MASK at load time; bits 1..5: standard encoder only)
     int capN = 0;
 };
 
 int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err);
 void lg_cnn_free(LgCnn* c);
-// patches: dense [N][9][32][32] (haloed_in = false) or haloed planes [N][9][34][36] with zero halos (what lg_select_grasp's
+// patches: dense [N][9][32][32] (haloed_in = false) or haloed planes [N][12][34][36] (planes 9..11 and all halos zero) (what lg_select_grasp's
 // gather writes directly; lg_cnn_halo_patch_floats() floats per patch)
 int lg_cnn_run(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err);
 size_t lg_cnn_halo_patch_floats(void);

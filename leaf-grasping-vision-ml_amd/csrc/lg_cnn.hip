@@ -19,10 +19,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef LG_W4_EXP
+#define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
+#endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue
 
 namespace {
 
@@ -41,12 +46,12 @@ constexpr int lg_plane(int wi) { return (wi + 2) * (wi + 4); }   // floats per h
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                  \
                                      (__attribute__((address_space(3))) void*)(dst), 4, 0, 0)
 
-// [N][9][32][32] (the C-ABI's patch layout) -> haloed [N][9][34][36]; the halo is never written
+// [N][9][32][32] (the C-ABI's patch layout) -> the first 9 of [N][12][34][36] haloed planes; halos and planes 9..11 are never written
 __global__ __launch_bounds__(256) void lg_repack_kernel(const float* __restrict__ in, float* __restrict__ out, long long nplanes) {
     const long long pl = blockIdx.x;
     if (pl >= nplanes) return;
     const float4* src = reinterpret_cast<const float4*>(in + pl * 1024);
-    float* dst = out + pl * lg_plane(32);
+    float* dst = out + ((pl / 9) * 12 + pl % 9) * lg_plane(32);
     const int t = threadIdx.x, y = t >> 3, x4 = (t & 7) * 4;
     const float4 v = src[t];
     float* d = dst + (y + 1) * lg_wp(32) + x4 + 1;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void lg_conv0_kernel(const float* __restric
     const int p = lane & 31, kh = lane >> 5;
     const int boff0 = (2 * wave) * WP + p, boff1 = (2 * wave + 1) * WP + p;
     const int aoff = lane & 31;
-    const float* in_n = in + (size_t)n * CIN * PLANE;
+    const float* in_n = in + (size_t)n * 12 * PLANE;   // 12 planes per haloed input patch (lg_cnn_halo_patch_floats)
 
     const float* src0[NIN];   // band 0 source of every staging slot; + ROWS * WP floats per band for real channels
     bool real[NIN];
@@ -511,6 +516,20 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
     }
 }
 
+// LDS fragment reads hipcc does not see (it drains lgkmcnt to 0 in front of every MFMA group of this kernel instead of counting):
+// the read and, later, a wait that names the destinations (so no consumer is scheduled above it) with K = the number of
+// THESE reads issued after the one waited for.  LDS operations complete in order, so compiler-issued LDS operations in
+// between only make the wait longer, never too short.
+typedef float lg_f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lg_lds_read16(lg_f32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void lg_lds_wait2(lg_f32x4& a, lg_f32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(K) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Winograd F(4x4,3x3):  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 6x6 input tile d / 4x4 output tile Y: 36 independent
 // contractions over the input channels, 4x fewer MFMA flops than the direct form (F(2x2,3x3): 2.25x).  Products and
@@ -518,10 +537,11 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
 // relative error on the logits (tests compare with the reference's fp64 logits at 1e-4; the F(2x2,3x3) and direct kernels
 // remain selectable as second opinions: LG_CNN_F23=1, LG_CNN_DIRECT=1).
 //
-// Workgroup = 512 threads = 8 waves = 64 output channels x 32 tiles x all 36 positions; chunks of 4 input channels
-// (one MFMA k-step).  Wave w owns channel block cb = w & 3 (16 channels) and tile block tb = w >> 2 (16 tiles): 36
-// accumulators (144 VGPRs); a lane ends with all 36 positions of its 4 (channel, tile) pairs, so the output transform,
-// bias, ReLU and the 2x2 max-pool need no exchange.
+// Work item = 64 output channels x 32 tiles x all 36 positions, in chunks of 4 input channels (one MFMA k-step).
+// Workgroup = 512 threads = 8 waves, PERSISTENT: one per CU, walking its items as ONE software pipeline over
+// (item, chunk) -- the staging of an item's first chunks runs under the previous item's last MFMAs.  Wave w owns channel
+// block cb = w & 3 (16 channels) and tile block tb = w >> 2 (16 tiles): 36 accumulators (144 VGPRs); a lane ends with all
+// 36 positions of its 4 (channel, tile) pairs, so the output transform, bias, ReLU and the 2x2 max-pool need no exchange.
 //   * A operand: the chunk's 36 KB block of U -- stored in global memory in exactly the order the fragments are read,
 //     [k-step][64-channel block][cb][position group of 4][lane = (k, channel)][4 positions] -- streams into a 2-stage LDS ring
 //     by 16-byte DMA (4.5 transfers per thread and chunk) and is shared by the two tile-block waves of a channel block:
@@ -529,17 +549,18 @@ __global__ __launch_bounds__(256, 2) void lg_wino_kernel(const float* __restrict
 //   * B operand: the band's haloed input rows of the chunk's 4 channels arrive by 16-byte DMA (2-3 transfers per thread),
 //     are transformed (V = B^T d B, work item = (channel, tile, row of V): 768 items per chunk on 512 threads) into
 //     V[tb][position group][lane = (k, tile)][4 positions] -- again one ds_read_b128 per 4 MFMAs, shared by 4 waves.
-//   The transform of chunk c + 1 is issued between the MFMAs of chunk c (its LDS reads first, so their latency hides
-//   behind matrix work; its VALU adds to the MFMA time -- f32 MFMA and VALU share the FMA lanes); ONE barrier per chunk.
+//   Inside a chunk the fragment reads run two position groups ahead of the MFMAs that use them (3-deep register ring,
+//   counted lgkmcnt waits) and the transform of the NEXT chunk is issued between them (its LDS reads first; its VALU
+//   adds to the MFMA time: f32 MFMA and VALU share the FMA lanes); ONE barrier per chunk.
 template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR>
 __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__ in, const float* __restrict__ U4,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N, int ntb) {
     constexpr int THREADS = 512;
     constexpr int KC = 4;
     constexpr int TC = WI / 4, TP = TC * TC;               // tile columns, tiles per patch
-    constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per workgroup
-    constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // workgroups (row bands) per patch
-    constexpr int TPB = 32 / PB;                           // tiles of one patch inside the workgroup
+    constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per item
+    constexpr int BPP = TP >= 32 ? TP / 32 : 1;            // items (row bands) per patch
+    constexpr int TPB = 32 / PB;                           // tiles of one patch inside the item
     constexpr int TROWS = TPB / TC;                        // tile rows per band
     constexpr int WP = lg_wp(WI), PLANE = lg_plane(WI);
     constexpr int RH = 4 * TROWS + 2;                      // staged haloed rows per channel and patch
@@ -562,41 +583,56 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // XCD-aware order (workgroups b, b + 8, ... share an XCD and its L2; an XCD starts them in the order of b / 8).  XCD x owns
-    // the tile blocks tb = 8 * local + x and all NCB channel blocks of them.  Small U (fits L2 beside the inputs): channel
-    // block fastest, the NCB readers of an input band run back to back.  Large U (layers 4-5: 4.7 / 9.4 MB against 4 MB of
-    // L2): channel block slowest, every CU of the XCD streams the SAME 64-channel slice of U while the XCD's input bands
-    // stream past once per slice.  The grid is 8 * ceil(ntb / 8) * NCB; workgroups past the last tile block leave at once.
+    // XCD-aware item order (workgroups b, b + 8, ... share an XCD and its L2).  XCD x owns the tile blocks 8 * local + x and all
+    // NCB channel blocks of them, as a list of ntbx * NCB items; its gx workgroups take list positions j, j + gx, j + 2 gx, ...
+    // so at any time they work on neighbouring positions.  Small U (fits L2 beside the inputs): channel block fastest, the NCB
+    // readers of an input band run back to back.  Large U (layers 4-5: 4.7 / 9.4 MB against 4 MB of L2): channel block
+    // slowest, every CU of the XCD streams the SAME 64-channel slice of U while the XCD's input bands stream past.
     const int ntbx = (ntb + 7) / 8;
-    const int xcd = blockIdx.x % 8, jx = blockIdx.x / 8;
-    const int cob = COB_MAJOR ? jx / ntbx : jx % NCB;
-    const int tbk = (COB_MAJOR ? jx % ntbx : jx / NCB) * 8 + xcd;
-    if (tbk >= ntb) return;
-    const int n0 = PB > 1 ? tbk * PB : tbk / BPP;
-    const int band = PB > 1 ? 0 : tbk % BPP;
-    const int y0 = band * 4 * TROWS;                       // first staged haloed row (= output row y0 - 1)
-    const int co0 = cob * 64;
+    const int xcd = blockIdx.x % 8, jx = blockIdx.x / 8, gx = gridDim.x / 8;
+    const int llen = ntbx * NCB;
+    const int ni = jx < llen ? (llen - jx + gx - 1) / gx : 0;      // items of this workgroup
+    if (ni == 0) return;
+    const int Q = ni * NC;                                          // chunks of this workgroup, all items
 
-    // ---- staging offsets
-    const float* in_n = in + (size_t)n0 * CIN * PLANE;
+    // ---- per-item geometry
+    struct Item { int cob, n0, band; };
+    auto item_at = [&](int i) {
+        const int p = jx + i * gx;
+        Item it;
+        it.cob = COB_MAJOR ? p / ntbx : p % NCB;
+        const int tbk = (COB_MAJOR ? p % ntbx : p / NCB) * 8 + xcd;   // tile blocks past ntb: patches >= N, nothing is stored
+        it.n0 = PB > 1 ? tbk * PB : tbk / BPP;
+        it.band = PB > 1 ? 0 : tbk % BPP;
+        return it;
+    };
+    // input stream (runs two chunks ahead of the MFMAs): source offsets of this thread's 16-byte pieces for the stream's item
+    const float* in_item = in;
     unsigned voff[NIN];
+    auto set_input_item = [&](int i) {
+        const Item it = item_at(i);
+        const int nb = it.n0 < N ? it.n0 : 0;                        // addressing stays inside the buffer for discarded items
+        in_item = in + (size_t)nb * CIN * PLANE;
+        const int y0 = it.band * 4 * TROWS;                           // first staged haloed row (= output row y0 - 1)
 #pragma unroll
-    for (int j = 0; j < NIN; j++) {
-        const int e = t + THREADS * j;
-        const int ci = e / (PB * PPC), r = e % (PB * PPC);
-        const int pb = r / PPC, piece = r % PPC;
-        const bool ok = e < NPIECE && n0 + pb < N;
-        voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
-    }
+        for (int j = 0; j < NIN; j++) {
+            const int e = t + THREADS * j;
+            const int ci = e / (PB * PPC), r = e % (PB * PPC);
+            const int pb = r / PPC, piece = r % PPC;
+            const bool ok = e < NPIECE && nb + pb < N;
+            voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
+        }
+    };
     auto issue_input = [&](int c, int stage) {
-        const char* in_c = (const char*)(in_n + (size_t)c * KC * PLANE);
+        if (LG_W4_EXP & 8) return;
+        const char* in_c = (const char*)(in_item + (size_t)c * KC * PLANE);
         float* sb = s_in + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < NIN; j++) LG_DMA16(in_c + voff[j], sb + 4 * (THREADS * j + 64 * wave));
     };
-    const float* u_blk = U4 + (size_t)cob * ABLK + 4 * t;   // + c * NCB * ABLK per chunk, + 2048 floats per transfer
-    auto issue_a = [&](int c, int stage) {
-        const float* src = u_blk + (size_t)c * NCB * ABLK;
+    auto issue_a = [&](int cob, int c, int stage) {
+        if (LG_W4_EXP & 4) return;
+        const float* src = U4 + (size_t)cob * ABLK + 4 * t + (size_t)c * NCB * ABLK;
         float* sb = s_a + stage * ABLK;
 #pragma unroll
         for (int j = 0; j < 4; j++) LG_DMA16(src + 2048 * j, sb + 4 * (THREADS * j + 64 * wave));
@@ -606,33 +642,62 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     // ---- transform items: (row i of V, channel k, tile tau); item = i * 128 + k * 32 + tau: thread t takes item t and threads
     //      0..255 item 512 + t, so a wave's 64 items share i (wave-uniform: scalar selects, no divergence).
     //      r[j] = sum_q coef[i][q] * d[rowsel[i][q]][j]  (row i of B^T d), then the same 1-D transform along j
-    const int i_a = wave >> 1, i_b = 4 + (wave >> 1);        // row of V of this wave's first / second item (SGPRs)
+    // Waves 4..7 have no second item: they redo their first one (same values to the same addresses) rather than branch --
+    // a branch around LDS operations makes hipcc drain lgkmcnt at the join instead of counting the fragment reads.
+    const int i_a = wave >> 1, i_b = wave < 4 ? 4 + (wave >> 1) : (wave >> 1);   // row of V of the first / second item (SGPRs)
     const int tk = ((wave & 1) << 1) | (lane >> 5), tau = lane & 31;
     const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WP + 4 * ((tau % TPB) % TC);
     const int tdst = (((tau >> 4) * 9) * 64 + (tk * 16 + (tau & 15))) * 4;
-    auto transform_load = [&](int i, int stage, f32x4 (&dl)[4], f32x2 (&dh)[4]) {
-        const float* sp = s_in + stage * STAGE + tsrc;
-        // rows of d entering row i of B^T d: i = 0: 0,2,4,(4)  i = 1..4: 1,2,3,4  i = 5: 1,3,5,(5)
-        const int rr[4] = {i == 0 ? 0 : 1, i == 0 ? 2 : (i == 5 ? 3 : 2), i == 0 ? 4 : (i == 5 ? 5 : 3), i == 0 ? 4 : (i == 5 ? 5 : 4)};
+    // Everything that depends on the row i is a wave-uniform table entry computed here, once: inside the chunk loop the
+    // transform is straight-line code (a scalar branch around LDS operations costs a full lgkmcnt drain at its join).
+    struct TRow { int ro[4]; float c[4]; int wo[3]; };
+    auto make_row = [&](int i) {
+        TRow r;
+        // rows of d entering row i of B^T d, and their coefficients: i = 0: 0,2,4,(4)  i = 1..4: 1,2,3,4  i = 5: 1,3,5,(5)
+        const int rr[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
+        const float cc[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f},
+                                {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, -5.f, 1.f, 0.f}};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float* p = sp + rr[q] * WP;                 // 16-byte aligned: tile columns start at multiples of 4 floats
+            int ro = 0; float c = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < 6; ii++) { ro = i == ii ? rr[ii][q] * WP : ro; c = i == ii ? cc[ii][q] : c; }
+            r.ro[q] = __builtin_amdgcn_readfirstlane(ro);
+            r.c[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c)));
+        }
+#pragma unroll
+        for (int m = 0; m < 3; m++) {          // positions 6i + 2m, 6i + 2m + 1: one aligned 8-byte store each
+            const int p = 6 * i + 2 * m;
+            r.wo[m] = __builtin_amdgcn_readfirstlane((p >> 2) * 256 + (p & 3));
+        }
+        return r;
+    };
+    const TRow row_a = make_row(i_a), row_b = make_row(i_b);
+    auto transform_load = [&](const TRow& tr, int stage, f32x4 (&dl)[4], f32x2 (&dh)[4]) {
+        if (LG_W4_EXP & 2) return;
+        const float* sp = s_in + stage * STAGE + tsrc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float* p = sp + tr.ro[q];                   // 16-byte aligned: tile columns start at multiples of 4 floats
             dl[q] = *reinterpret_cast<const f32x4*>(p);
             dh[q] = *reinterpret_cast<const f32x2*>(p + 4);
         }
     };
-    auto transform_store = [&](int i, int vstage, const f32x4 (&dl)[4], const f32x2 (&dh)[4]) {
-        // coefficients of the four rows (wave-uniform)
-        const float c0 = i == 0 ? 4.f : i == 1 ? -4.f : i == 2 ? 4.f : i == 3 ? -2.f : i == 4 ? 2.f : 4.f;
-        const float c1 = i == 0 ? -5.f : i == 1 ? -4.f : i == 2 ? -4.f : i == 3 ? -1.f : i == 4 ? -1.f : -5.f;
-        const float c2 = i == 0 ? 1.f : i == 1 ? 1.f : i == 2 ? -1.f : i == 3 ? 2.f : i == 4 ? -2.f : 1.f;
-        const float c3 = (i == 0 || i == 5) ? 0.f : 1.f;
+    auto transform_store = [&](const TRow& tr, int vstage, const f32x4 (&dl)[4], const f32x2 (&dh)[4]) {
+        if (LG_W4_EXP & 2) return;
+        float* g0 = s_v + vstage * VBLK + tdst;              // lane (k, tau & 15) of tile block tau >> 4
+        if (LG_W4_EXP & 1) {
+            *reinterpret_cast<f32x2*>(g0 + tr.wo[0]) = (f32x2){dl[0][0], dl[1][1]};
+            *reinterpret_cast<f32x2*>(g0 + tr.wo[1]) = (f32x2){dl[2][2], dl[3][3]};
+            *reinterpret_cast<f32x2*>(g0 + tr.wo[2]) = dh[0] + dh[1] + dh[2] + dh[3];
+            return;
+        }
         float r[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const float d0 = j < 4 ? dl[0][j & 3] : dh[0][j & 1], d1 = j < 4 ? dl[1][j & 3] : dh[1][j & 1],
                         d2 = j < 4 ? dl[2][j & 3] : dh[2][j & 1], d3 = j < 4 ? dl[3][j & 3] : dh[3][j & 1];
-            r[j] = fmaf(c0, d0, fmaf(c1, d1, fmaf(c2, d2, c3 * d3)));
+            r[j] = fmaf(tr.c[0], d0, fmaf(tr.c[1], d1, fmaf(tr.c[2], d2, tr.c[3] * d3)));
         }
         float v[6];
         v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
@@ -641,125 +706,150 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         const float cc = r[4] - r[2], e = 2.f * (r[3] - r[1]);
         v[3] = cc + e; v[4] = cc - e;
         v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
-        // positions 6i .. 6i+5 of lane (k, tau & 15) in tile block tau >> 4; i even: 6i % 4 == 0, i odd: 6i % 4 == 2
-        float* g0 = s_v + vstage * VBLK + tdst + ((6 * i) >> 2) * 256;
-        if ((i & 1) == 0) {
-            *reinterpret_cast<f32x4*>(g0) = (f32x4){v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x2*>(g0 + 256) = (f32x2){v[4], v[5]};
-        } else {
-            *reinterpret_cast<f32x2*>(g0 + 2) = (f32x2){v[0], v[1]};
-            *reinterpret_cast<f32x4*>(g0 + 256) = (f32x4){v[2], v[3], v[4], v[5]};
-        }
+        *reinterpret_cast<f32x2*>(g0 + tr.wo[0]) = (f32x2){v[0], v[1]};
+        *reinterpret_cast<f32x2*>(g0 + tr.wo[1]) = (f32x2){v[2], v[3]};
+        *reinterpret_cast<f32x2*>(g0 + tr.wo[2]) = (f32x2){v[4], v[5]};
     };
 
     const int cb = wave & 3, tbw = wave >> 2;
     const float* const a_rd = s_a + ((cb * 9) * 64 + lane) * 4;
     const float* const b_rd = s_v + ((tbw * 9) * 64 + lane) * 4;
-    f32x4 acc[36];
-#pragma unroll
-    for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto mfma_groups = [&](int stage, int pg0, int pg1) {
-#pragma unroll
-        for (int pg = pg0; pg < pg1; pg++) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(a_rd + stage * ABLK + pg * 256);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(b_rd + stage * VBLK + pg * 256);
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc[4 * pg + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[4 * pg + e], 0, 0, 0);
+    // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
+    int in_i = 0, in_c = 0;                                 // (item, chunk) the input stream issues next
+    auto input_next = [&](int stage) {
+        issue_input(in_c, stage);
+        if (++in_c == NC) {
+            in_c = 0;
+            if (++in_i < ni) set_input_item(in_i);
         }
     };
-
-    // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
-    issue_input(0, 0);
-    issue_a(0, 0);
+    set_input_item(0);
+    input_next(0);
+    issue_a(item_at(0).cob, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     {
         f32x4 dl[4];
         f32x2 dh[4];
-        transform_load(i_a, 0, dl, dh);
-        transform_store(i_a, 0, dl, dh);
-        if (wave < 4) {
-            transform_load(i_b, 0, dl, dh);
-            transform_store(i_b, 0, dl, dh);
-        }
+        transform_load(row_a, 0, dl, dh);
+        transform_store(row_a, 0, dl, dh);
+        transform_load(row_b, 0, dl, dh);
+        transform_store(row_b, 0, dl, dh);
     }
-    if (NC > 1) issue_input(1, 1);
+    if (Q > 1) input_next(1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+    int q = 0;                                              // chunk counter over all items (stage parity)
 #pragma unroll 1
-    for (int c = 0; c < NC; c++) {
-        const int st = c & 1;
-        const bool more = c + 1 < NC;
-        if (more) issue_a(c + 1, st ^ 1);
-        if (c + 2 < NC) issue_input(c + 2, st);            // stage st: read by the transform of chunk c, one iteration ago
-        f32x4 dl[4];
-        f32x2 dh[4];
-        if (more) transform_load(i_a, st ^ 1, dl, dh);     // LDS reads first: their latency hides behind the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_groups(st, 0, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) transform_store(i_a, st ^ 1, dl, dh);
-        if (more && wave < 4) transform_load(i_b, st ^ 1, dl, dh);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_groups(st, 3, 6);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && wave < 4) transform_store(i_b, st ^ 1, dl, dh);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_groups(st, 6, 9);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    for (int it_i = 0; it_i < ni; it_i++) {
+        const Item cur = item_at(it_i);
+        const int cob_next = it_i + 1 < ni ? item_at(it_i + 1).cob : cur.cob;
+        f32x4 acc[36];
+#pragma unroll
+        for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < NC; c++, q++) {
+            const int st = q & 1;
+            const bool more = q + 1 < Q;
+            if (more) issue_a(c + 1 < NC ? cur.cob : cob_next, c + 1 < NC ? c + 1 : 0, st ^ 1);
+            if (q + 2 < Q) input_next(st);                   // stage st: read by the transform of chunk q, one iteration ago
+            // Fragment ring: position group pg uses slot pg % 3, its reads are issued two groups ahead of its MFMAs; every wait
+            // leaves the (up to) 4 fragment reads issued after the awaited pair in flight.  The transform of the next chunk sits between the groups: its LDS
+            // reads are issued first (hipcc drains lgkmcnt before their use: by then their latency has passed behind MFMAs).
+            f32x4 fa[3] = {}, fb[3] = {};
+            const unsigned ap = (unsigned)(size_t)(a_rd + st * ABLK), bp = (unsigned)(size_t)(b_rd + st * VBLK);
+            f32x4 dl[4];
+            f32x2 dh[4];
+            transform_load(row_a, st ^ 1, dl, dh);           // (after the very last chunk: stale bytes into an unused V stage)
+#define LG_FRAG(PG) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], ap); lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], bp); }
+#define LG_MM(PG)                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    if (!(LG_W4_EXP & 32)) _Pragma("unroll") for (int e = 0; e < 4; e++)                                                 \
+        acc[4 * (PG) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[(PG) % 3][e], fb[(PG) % 3][e], acc[4 * (PG) + e], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0)   /* hipcc moves register-only instructions across asm statements, the barrier included */
+            LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
+            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
+            LG_FRAG(3);
+            lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
+            __builtin_amdgcn_sched_barrier(0);
+            transform_store(row_a, st ^ 1, dl, dh);
+            transform_load(row_b, st ^ 1, dl, dh);
+            __builtin_amdgcn_sched_barrier(0);
+            LG_FRAG(4);
+            lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
+            LG_FRAG(5);
+            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
+            LG_FRAG(6);
+            lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
+            LG_FRAG(7);
+            lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
+            __builtin_amdgcn_sched_barrier(0);
+            transform_store(row_b, st ^ 1, dl, dh);
+            __builtin_amdgcn_sched_barrier(0);
+            LG_FRAG(8);
+            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
+            lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
+            lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+#undef LG_FRAG
+#undef LG_MM
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
 
-    // ---- epilogue: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
-    constexpr int WO = POOL ? WI / 2 : WI;
-    constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
-    constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
-    constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
-    const int etau = 16 * tbw + (lane & 15);
-    const int epb = etau / TPB, etl = etau % TPB;
-    const int n = n0 + epb;
-    const int trg = band * TROWS + etl / TC, tcg = etl % TC;
+        // ---- item done: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
+        if (LG_W4_EXP & 64) { if (acc[0][0] == 123.456f) out[t] = acc[1][1] + acc[35][3]; continue; }
+        constexpr int WO = POOL ? WI / 2 : WI;
+        constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
+        constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
+        constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
+        const int etau = 16 * tbw + (lane & 15);
+        const int epb = etau / TPB, etl = etau % TPB;
+        const int n = cur.n0 + epb;
+        const int trg = cur.band * TROWS + etl / TC, tcg = etl % TC;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int co = co0 + 16 * cb + 4 * (lane >> 4) + r;
-        // stage 1 over the rows i of M (for every column j): s[p][j] = sum_i AT[p][i] m[i][j]
-        float s[4][6];
+        for (int r = 0; r < 4; r++) {
+            const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
+            float s[4][6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r],
-                        m5 = acc[30 + j][r];
-            const float t1 = m1 + m2, t2 = m1 - m2, t3 = m3 + m4, t4 = m3 - m4;
-            s[0][j] = m0 + t1 + t3;
-            s[1][j] = fmaf(2.f, t4, t2);
-            s[2][j] = fmaf(4.f, t3, t1);
-            s[3][j] = fmaf(8.f, t4, t2) + m5;
-        }
-        const float bv = bias[co];
-        float y[4][4];
+            for (int j = 0; j < 6; j++) {
+                const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r],
+                            m5 = acc[30 + j][r];
+                const float t1 = m1 + m2, t2 = m1 - m2, t3 = m3 + m4, t4 = m3 - m4;
+                s[0][j] = m0 + t1 + t3;
+                s[1][j] = fmaf(2.f, t4, t2);
+                s[2][j] = fmaf(4.f, t3, t1);
+                s[3][j] = fmaf(8.f, t4, t2) + m5;
+            }
+            const float bv = bias[co];
+            float y[4][4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
-            y[p][0] = s[p][0] + t1 + t3 + bv;
-            y[p][1] = fmaf(2.f, t4, t2) + bv;
-            y[p][2] = fmaf(4.f, t3, t1) + bv;
-            y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
-        }
-        if (n < N) {
-            float* o = out + ((size_t)n * COUT + co) * OPL + OO;
-            if (POOL) {
+            for (int p = 0; p < 4; p++) {
+                const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
+                y[p][0] = s[p][0] + t1 + t3 + bv;
+                y[p][1] = fmaf(2.f, t4, t2) + bv;
+                y[p][2] = fmaf(4.f, t3, t1) + bv;
+                y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
+            }
+            if (n < N) {
+                float* o = out + ((size_t)n * COUT + co) * OPL + OO;
+                // One vector store per tile row (interior pixels start at an odd column: 4-byte aligned 8 / 16-byte stores,
+                // which the hardware takes): a wave instruction then covers whole 64-128-byte runs of the plane.  Scattered
+                // dword stores (64 lines per instruction, one line per clock in the vector L1) cost 1.9 of 5.3 ms.
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                if (POOL) {
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
-                    const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
-                    float* o0 = o + (2 * trg + p) * OP + 2 * tcg;
-                    o0[0] = v0; o0[1] = v1;
-                }
-            } else {
+                    for (int p = 0; p < 2; p++) {
+                        const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
+                        const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
+                        *reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg) = (f32x2u){v0, v1};
+                    }
+                } else {
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    float* o0 = o + (4 * trg + p) * OP + 4 * tcg;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) o0[q] = fmaxf(y[p][q], 0.f);
+                    for (int p = 0; p < 4; p++)
+                        *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
+                            (f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)};
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
         }
     }
 }
@@ -924,11 +1014,19 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const f
     return false;
 }
 
+#define LG_WINO4_L0_SHAPES(X) X(12, 64, 32, false) X(12, 128, 32, false)
 bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
                      float* out, int N, hipStream_t s) {
     const int tp = (wi / 4) * (wi / 4);
     const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
-    const int grid = 8 * ((ntb + 7) / 8) * (cout / 64);
+    // persistent: one 512-thread workgroup per CU (140-156 KB of LDS each), a multiple of 8 so every XCD gets the same number
+    static const int num_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n >= 8 ? n / 8 * 8 : 8;
+    }();
+    const long long items8 = (long long)((ntb + 7) / 8) * (cout / 64);   // items per XCD
+    const int grid = 8 * (int)std::min<long long>(items8, num_cu / 8);
 #define X(CI, CO, W_, P)                                                                                              \
     if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
         constexpr bool CM = 36LL * CI * CO * 4 > 3 * 1024 * 1024;                                                     \
@@ -939,6 +1037,7 @@ bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const 
         return true;                                                                                                  \
     }
     LG_WINO_SHAPES(X)
+    LG_WINO4_L0_SHAPES(X)
 #undef X
     return false;
 }
@@ -1048,11 +1147,14 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
             }
             rc = upload(&c->uwino[L], uw, err);
             if (rc) return rc;
+        }
+        {
             // F(4x4,3x3) weights U = G g G^T (6x6) of the BN-folded kernel in the order lg_wino4_kernel's A fragments are read:
             // [k-step = ci/4][64-channel block][cb = (co%64)/16][position group pg = pos/4][lane = (ci%4)*16 + co%16][pos%4]
             static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-            std::vector<float> u4((size_t)l.cinp * l.coutp * 36, 0.0f);
+            const int cinp4 = L == 0 ? 12 : l.cinp;   // layer 0: 9 feature planes + 3 zero planes
+            std::vector<float> u4((size_t)cinp4 * l.coutp * 36, 0.0f);
             const int ncb = l.coutp / 64;
             for (int co = 0; co < l.cout; co++) {
                 for (int ci = 0; ci < l.cin; ci++) {
@@ -1124,14 +1226,15 @@ int lg_cnn_upload(LgCnn* c, const lg_cnn_weights* w, std::string* err) {
     // LG_CNN_DIRECT=1 direct implicit GEMM for every layer; LG_CNN_WINO_MASK=<bits> bit L = layer L on Winograd
     // LG_CNN_F23=1 the F(2x2,3x3) Winograd kernels instead of F(4x4,3x3)
     c->use_f23 = getenv("LG_CNN_F23") != nullptr;
-    c->wino_mask = getenv("LG_CNN_DIRECT") ? 0 : 0x3e;
-    if (const char* e = getenv("LG_CNN_WINO_MASK")) c->wino_mask = atoi(e) & 0x3e;
+    c->wino_mask = getenv("LG_CNN_DIRECT") ? 0 : 0x3f;
+    if (const char* e = getenv("LG_CNN_WINO_MASK")) c->wino_mask = atoi(e) & 0x3f;
     c->loaded = true;
     return LG_OK;
 }
 
 
-size_t lg_cnn_halo_patch_floats(void) { return (size_t)9 * lg_plane(32); }
+// haloed input patch: the 9 feature planes + 3 zero planes (layer 0 runs on the Winograd kernel in chunks of 4 channels)
+size_t lg_cnn_halo_patch_floats(void) { return (size_t)12 * lg_plane(32); }
 
 // activation buffers, one per layer (fixed geometry: the zero halos are written once, at allocation)
 static int ensure_act(LgCnn* c, int N, hipStream_t s, std::string* err) {
@@ -1183,7 +1286,10 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         hipLaunchKernelGGL(lg_repack_kernel, dim3((unsigned)(N * 9)), dim3(256), 0, s, patches, c->in_halo, (long long)N * 9);
         x = c->in_halo;
     }
-    if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
+    // layer 0: the F(4x4,3x3) kernel on 12 input planes (3 chunks); the direct 9-channel kernel with LG_CNN_DIRECT / _F23 / mask bit 0 clear
+    if (!c->use_f23 && (c->wino_mask & 1))
+        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, s);
+    else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
     else launch_conv0<128>(x, c, c->act[0], N, s);
     const float* cur = c->act[0];
     if (c->standard) {

@@ -1180,7 +1180,7 @@ void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth,
 // replicate-padded (:392-445); channel 0 depth and channels 2..8 (sdf, approach, flatness, isolation,
 // distance, accessibility, stem) are min-max normalised per patch when max > min; channel 1 = raw mask.
 struct LgGatherMaps { const float* p[7]; };
-// HALO: write the interior of haloed planes [9][34][36] (pixel (y,x) at [y+1][x+1]; the CNN's staging layout, lg_cnn.hip;
+// HALO: write the interior of the first 9 of the 12 haloed planes [12][34][36] (pixel (y,x) at [y+1][x+1]; the CNN's staging layout, lg_cnn.hip;
 // the halo itself is zeroed once when the workspace is allocated) instead of dense [9][32][32].
 template <bool HALO>
 __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict__ depth,
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
     constexpr int PL = HALO ? 34 * 36 : 1024, RP = HALO ? 36 : 32, O0 = HALO ? 37 : 0;
     const int ci = blockIdx.x, frame = blockIdx.y;
     const int t = threadIdx.x;
-    float* outp = patches + ((size_t)frame * k + ci) * 9 * PL + O0;
+    float* outp = patches + ((size_t)frame * k + ci) * (HALO ? 12 : 9) * PL + O0;   // haloed patches carry 3 more (zero) planes
     if (ci >= n[frame]) {
         for (int c = 0; c < 9; c++)
             for (int i = t; i < 1024; i += 256) outp[c * PL + (i >> 5) * RP + (i & 31)] = 0.0f;
