@@ -550,12 +550,11 @@ __device__ __forceinline__ void lg_lds_wait2(lg_f32x4& a, lg_f32x4& b) {
 //     are transformed (V = B^T d B, work item = (channel, tile, row of V): 768 items per chunk on 512 threads) into
 //     V[tb][position group][lane = (k, tile)][4 positions] -- again one ds_read_b128 per 4 MFMAs, shared by 4 waves.
 //   Inside a chunk the fragment reads run two position groups ahead of the MFMAs that use them (3-deep register ring,
-//   counted lgkmcnt waits) and the transform of the NEXT chunk is issued between them (its LDS reads first; its VALU
-//   adds to the MFMA time: f32 MFMA and VALU share the FMA lanes); ONE barrier per chunk.
+//   hand-counted lgkmcnt waits); the work for the NEXT chunk is split by role between the two waves of every SIMD (see
+//   "roles" in the kernel): one transforms, the other issues the DMA transfers; ONE barrier per chunk.
 template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR>
 __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__ in, const float* __restrict__ U4,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N, int ntb) {
-    constexpr int THREADS = 512;
     constexpr int KC = 4;
     constexpr int TC = WI / 4, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per item
@@ -567,8 +566,8 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     constexpr int RS = RH * WP, S = PB * RS;
     constexpr int PPC = RS / 4;
     constexpr int NPIECE = KC * PB * PPC;
-    constexpr int NIN = (NPIECE + THREADS - 1) / THREADS;
-    constexpr int STAGE = NIN * THREADS * 4;               // floats per input stage
+    constexpr int NIN = (NPIECE + 255) / 256;              // input transfers per chunk and thread of the four staging waves
+    constexpr int STAGE = NIN * 256 * 4;                   // floats per input stage
     constexpr int ABLK = 64 * 36 * KC;                     // 9216 floats of U per (k-step, 64-channel block)
     constexpr int VBLK = 32 * 36 * KC;                     // 4608 floats of V per chunk
     constexpr int NCB = COUT / 64;
@@ -576,7 +575,12 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     static_assert(CIN % KC == 0 && COUT % 64 == 0 && TPB % TC == 0 && (RS % 4) == 0 && TROWS >= 1, "shape");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) float s_mem[2 * ABLK + 2 * VBLK + 2 * STAGE];
+    // Input ring: 3 stages where they fit in the 160 KB (every shape but the 4x4 images of the deepest encoder variant).  The
+    // input rows come from HBM (the previous layer's output, GBs per layer): with 3 stages the transfers of chunk q + 3 are
+    // issued during chunk q and only have to land by the END of chunk q + 1 (a counted vmcnt wait leaves them in flight across
+    // one barrier); with 2 stages they have to land within the chunk that issues them and every chunk pays an HBM round trip.
+    constexpr int NSTG = (2 * ABLK + 2 * VBLK + 3 * STAGE) * 4 <= 160 * 1024 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * ABLK + 2 * VBLK + NSTG * STAGE];
     float* const s_a = s_mem;
     float* const s_v = s_mem + 2 * ABLK;
     float* const s_in = s_mem + 2 * ABLK + 2 * VBLK;
@@ -595,7 +599,6 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     if (ni == 0) return;
     const int Q = ni * NC;                                          // chunks of this workgroup, all items
 
-    // ---- per-item geometry
     struct Item { int cob, n0, band; };
     auto item_at = [&](int i) {
         const int p = jx + i * gx;
@@ -606,252 +609,306 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         it.band = PB > 1 ? 0 : tbk % BPP;
         return it;
     };
-    // input stream (runs two chunks ahead of the MFMAs): source offsets of this thread's 16-byte pieces for the stream's item
-    const float* in_item = in;
-    unsigned voff[NIN];
-    auto set_input_item = [&](int i) {
-        const Item it = item_at(i);
-        const int nb = it.n0 < N ? it.n0 : 0;                        // addressing stays inside the buffer for discarded items
-        in_item = in + (size_t)nb * CIN * PLANE;
-        const int y0 = it.band * 4 * TROWS;                           // first staged haloed row (= output row y0 - 1)
-#pragma unroll
-        for (int j = 0; j < NIN; j++) {
-            const int e = t + THREADS * j;
-            const int ci = e / (PB * PPC), r = e % (PB * PPC);
-            const int pb = r / PPC, piece = r % PPC;
-            const bool ok = e < NPIECE && nb + pb < N;
-            voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
-        }
-    };
-    auto issue_input = [&](int c, int stage) {
-        if (LG_W4_EXP & 8) return;
-        const char* in_c = (const char*)(in_item + (size_t)c * KC * PLANE);
-        float* sb = s_in + stage * STAGE;
-#pragma unroll
-        for (int j = 0; j < NIN; j++) LG_DMA16(in_c + voff[j], sb + 4 * (THREADS * j + 64 * wave));
-    };
-    auto issue_a = [&](int cob, int c, int stage) {
-        if (LG_W4_EXP & 4) return;
-        const float* src = U4 + (size_t)cob * ABLK + 4 * t + (size_t)c * NCB * ABLK;
-        float* sb = s_a + stage * ABLK;
-#pragma unroll
-        for (int j = 0; j < 4; j++) LG_DMA16(src + 2048 * j, sb + 4 * (THREADS * j + 64 * wave));
-        if (wave < 4) LG_DMA16(src + 2048 * 4, sb + 4 * (THREADS * 4 + 64 * wave));   // 2304 pieces = 4.5 x 512
-    };
 
-    // ---- transform items: (row i of V, channel k, tile tau); item = i * 128 + k * 32 + tau: thread t takes item t and threads
-    //      0..255 item 512 + t, so a wave's 64 items share i (wave-uniform: scalar selects, no divergence).
-    //      r[j] = sum_q coef[i][q] * d[rowsel[i][q]][j]  (row i of B^T d), then the same 1-D transform along j
-    // Waves 4..7 have no second item: they redo their first one (same values to the same addresses) rather than branch --
-    // a branch around LDS operations makes hipcc drain lgkmcnt at the join instead of counting the fragment reads.
-    const int i_a = wave >> 1, i_b = wave < 4 ? 4 + (wave >> 1) : (wave >> 1);   // row of V of the first / second item (SGPRs)
-    const int tk = ((wave & 1) << 1) | (lane >> 5), tau = lane & 31;
-    const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WP + 4 * ((tau % TPB) % TC);
-    const int tdst = (((tau >> 4) * 9) * 64 + (tk * 16 + (tau & 15))) * 4;
-    // Everything that depends on the row i is a wave-uniform table entry computed here, once: inside the chunk loop the
-    // transform is straight-line code (a scalar branch around LDS operations costs a full lgkmcnt drain at its join).
-    struct TRow { int ro[4]; float c[4]; int wo[3]; };
-    auto make_row = [&](int i) {
-        TRow r;
-        // rows of d entering row i of B^T d, and their coefficients: i = 0: 0,2,4,(4)  i = 1..4: 1,2,3,4  i = 5: 1,3,5,(5)
-        const int rr[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
-        const float cc[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f},
-                                {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, -5.f, 1.f, 0.f}};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int ro = 0; float c = 0.f;
-#pragma unroll
-            for (int ii = 0; ii < 6; ii++) { ro = i == ii ? rr[ii][q] * WP : ro; c = i == ii ? cc[ii][q] : c; }
-            r.ro[q] = __builtin_amdgcn_readfirstlane(ro);
-            r.c[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c)));
-        }
-#pragma unroll
-        for (int m = 0; m < 3; m++) {          // positions 6i + 2m, 6i + 2m + 1: one aligned 8-byte store each
-            const int p = 6 * i + 2 * m;
-            r.wo[m] = __builtin_amdgcn_readfirstlane((p >> 2) * 256 + (p & 3));
-        }
-        return r;
-    };
-    const TRow row_a = make_row(i_a), row_b = make_row(i_b);
-    auto transform_load = [&](const TRow& tr, int stage, f32x4 (&dl)[4], f32x2 (&dh)[4]) {
-        if (LG_W4_EXP & 2) return;
-        const float* sp = s_in + stage * STAGE + tsrc;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float* p = sp + tr.ro[q];                   // 16-byte aligned: tile columns start at multiples of 4 floats
-            dl[q] = *reinterpret_cast<const f32x4*>(p);
-            dh[q] = *reinterpret_cast<const f32x2*>(p + 4);
-        }
-    };
-    auto transform_store = [&](const TRow& tr, int vstage, const f32x4 (&dl)[4], const f32x2 (&dh)[4]) {
-        if (LG_W4_EXP & 2) return;
-        float* g0 = s_v + vstage * VBLK + tdst;              // lane (k, tau & 15) of tile block tau >> 4
-        if (LG_W4_EXP & 1) {
-            *reinterpret_cast<f32x2*>(g0 + tr.wo[0]) = (f32x2){dl[0][0], dl[1][1]};
-            *reinterpret_cast<f32x2*>(g0 + tr.wo[1]) = (f32x2){dl[2][2], dl[3][3]};
-            *reinterpret_cast<f32x2*>(g0 + tr.wo[2]) = dh[0] + dh[1] + dh[2] + dh[3];
-            return;
-        }
-        float r[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const float d0 = j < 4 ? dl[0][j & 3] : dh[0][j & 1], d1 = j < 4 ? dl[1][j & 3] : dh[1][j & 1],
-                        d2 = j < 4 ? dl[2][j & 3] : dh[2][j & 1], d3 = j < 4 ? dl[3][j & 3] : dh[3][j & 1];
-            r[j] = fmaf(tr.c[0], d0, fmaf(tr.c[1], d1, fmaf(tr.c[2], d2, tr.c[3] * d3)));
-        }
-        float v[6];
-        v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
-        const float a = fmaf(-4.f, r[2], r[4]), b = fmaf(-4.f, r[1], r[3]);
-        v[1] = a + b; v[2] = a - b;
-        const float cc = r[4] - r[2], e = 2.f * (r[3] - r[1]);
-        v[3] = cc + e; v[4] = cc - e;
-        v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
-        *reinterpret_cast<f32x2*>(g0 + tr.wo[0]) = (f32x2){v[0], v[1]};
-        *reinterpret_cast<f32x2*>(g0 + tr.wo[1]) = (f32x2){v[2], v[3]};
-        *reinterpret_cast<f32x2*>(g0 + tr.wo[2]) = (f32x2){v[4], v[5]};
-    };
-
+    // MFMA roles: channel block cb, tile block tbw; fragment addresses
     const int cb = wave & 3, tbw = wave >> 2;
     const float* const a_rd = s_a + ((cb * 9) * 64 + lane) * 4;
     const float* const b_rd = s_v + ((tbw * 9) * 64 + lane) * 4;
-    // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
-    int in_i = 0, in_c = 0;                                 // (item, chunk) the input stream issues next
-    auto input_next = [&](int stage) {
-        issue_input(in_c, stage);
-        if (++in_c == NC) {
-            in_c = 0;
-            if (++in_i < ni) set_input_item(in_i);
-        }
-    };
-    set_input_item(0);
-    input_next(0);
-    issue_a(item_at(0).cob, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    {
-        f32x4 dl[4];
-        f32x2 dh[4];
-        transform_load(row_a, 0, dl, dh);
-        transform_store(row_a, 0, dl, dh);
-        transform_load(row_b, 0, dl, dh);
-        transform_store(row_b, 0, dl, dh);
-    }
-    if (Q > 1) input_next(1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    int q = 0;                                              // chunk counter over all items (stage parity)
-#pragma unroll 1
-    for (int it_i = 0; it_i < ni; it_i++) {
-        const Item cur = item_at(it_i);
-        const int cob_next = it_i + 1 < ni ? item_at(it_i + 1).cob : cur.cob;
-        f32x4 acc[36];
+    // ================================================================================================ roles
+    // Waves w and w + 4 share a SIMD.  Both run the same MFMA sequence on their own (channel block, tile block); beside it
+    //   waves 0..3 TRANSFORM: wave w turns channel k = 2 (w >> 1) + (lane >> 5) of the NEXT chunk into rows 3 (w & 1) ..
+    //              3 (w & 1) + 2 of V for tile lane & 31 (the half is wave-uniform: straight-line code per half, the row
+    //              stage computed only for the rows the half needs: 72 VALU per thread and chunk, no redundancy);
+    //   waves 4..7 STAGE:     they issue every LDS-DMA transfer (U block of the next chunk, input rows of the chunk after),
+    //              a few after each of the first MFMA groups, so the transfers' issue time hides behind matrix work and the
+    //              last one has half a chunk to land.
+    // The two roles are two copies of the whole item loop (accumulators never cross a role join); both meet at the same
+    // barriers: two in the prologue, one per chunk.
+    auto role = [&](auto is_t_tag) {
+        constexpr bool IS_T = decltype(is_t_tag)::value;
+        const int dw = wave - 4;                                // staging wave index (IS_T == false)
+
+        // ---- staging state (waves 4..7)
+        const float* in_item = in;
+        unsigned voff[NIN];
+        int in_i = 0, in_c = 0;                                 // (item, chunk) the input stream issues next
+        auto set_input_item = [&](int i) {
+            const Item it = item_at(i);
+            const int nb = it.n0 < N ? it.n0 : 0;               // addressing stays inside the buffer for discarded items
+            in_item = in + (size_t)nb * CIN * PLANE;
+            const int y0 = it.band * 4 * TROWS;                  // first staged haloed row (= output row y0 - 1)
 #pragma unroll
-        for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NIN; j++) {
+                const int e = (j * 4 + dw) * 64 + lane;
+                const int ci = e / (PB * PPC), r = e % (PB * PPC);
+                const int pb = r / PPC, piece = r % PPC;
+                const bool ok = e < NPIECE && nb + pb < N;
+                voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
+            }
+        };
+        // transfer j of the input chunk the stream points at (then the stream advances after the last one)
+        auto input_piece = [&](int j, int stage) {
+            if (LG_W4_EXP & 8) return;
+            const char* in_c_ptr = (const char*)(in_item + (size_t)in_c * KC * PLANE);
+            LG_DMA16(in_c_ptr + voff[j], s_in + stage * STAGE + 4 * ((j * 4 + dw) * 64));
+        };
+        auto input_advance = [&]() {
+            if (++in_c == NC) {
+                in_c = 0;
+                if (++in_i < ni) set_input_item(in_i);
+            }
+        };
+        // transfer j (0..8) of the A block of (cob, chunk c): 2304 16-byte pieces = 9 x 4 waves x 64 lanes
+        auto a_piece = [&](int j, const float* ablk, int stage) {
+            if (LG_W4_EXP & 4) return;
+            LG_DMA16(ablk + 4 * ((j * 4 + dw) * 64 + lane), s_a + stage * ABLK + 4 * ((j * 4 + dw) * 64));
+        };
+
+        // ---- transform state (waves 0..3): channel tk, tile tau, half th (rows 3 th .. 3 th + 2 of V)
+        const int th = wave & 1;
+        const int tk = ((wave >> 1) << 1) | (lane >> 5), tau = lane & 31;
+        const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WP + 4 * ((tau % TPB) % TC) + th * WP;  // half 1 starts at row 1
+        const int tdst = (((tau >> 4) * 9) * 64 + (tk * 16 + (tau & 15))) * 4;
+        // rows th .. th + 4 of the 6x6 tile (half 0 needs rows 0..4, half 1 rows 1..5)
+        auto transform_load = [&](int stage, f32x4 (&dl)[5], f32x2 (&dh)[5]) {
+            if (LG_W4_EXP & 2) return;
+            const float* sp = s_in + stage * STAGE + tsrc;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                dl[q] = *reinterpret_cast<const f32x4*>(sp + q * WP);      // 16-byte aligned: tile columns start at multiples of 4
+                dh[q] = *reinterpret_cast<const f32x2*>(sp + q * WP + 4);
+            }
+        };
+        auto col6 = [](const float (&r)[6], float (&v)[6]) {   // 1-D transform B^T of a 6-vector (12 VALU)
+            v[0] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+            const float a = fmaf(-4.f, r[2], r[4]), b = fmaf(-4.f, r[1], r[3]);
+            v[1] = a + b; v[2] = a - b;
+            const float cc = r[4] - r[2], e = r[3] - r[1];
+            v[3] = fmaf(2.f, e, cc); v[4] = fmaf(-2.f, e, cc);
+            v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
+        };
+        auto transform_store = [&](int vstage, const f32x4 (&dl)[5], const f32x2 (&dh)[5]) {
+            if (LG_W4_EXP & 2) return;
+            float* g0 = s_v + vstage * VBLK + tdst;             // lane (k, tau & 15) of tile block tau >> 4; position p at (p >> 2) * 256 + (p & 3)
+            auto D = [&](int q, int j) { return j < 4 ? dl[q][j & 3] : dh[q][j & 1]; };
+            float r[3][6];
+            if (th == 0) {      // rows 0,1,2 of B^T d from tile rows 0..4 (= loaded rows 0..4)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    r[0][j] = fmaf(4.f, D(0, j), fmaf(-5.f, D(2, j), D(4, j)));
+                    const float a = fmaf(-4.f, D(2, j), D(4, j)), b = fmaf(-4.f, D(1, j), D(3, j));
+                    r[1][j] = a + b; r[2][j] = a - b;
+                }
+            } else {            // rows 3,4,5 from tile rows 1..5 (= loaded rows 0..4)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const float cc = D(3, j) - D(1, j), e = D(2, j) - D(0, j);
+                    r[0][j] = fmaf(2.f, e, cc); r[1][j] = fmaf(-2.f, e, cc);
+                    r[2][j] = fmaf(4.f, D(0, j), fmaf(-5.f, D(2, j), D(4, j)));
+                }
+            }
+            float v[3][6];
+#pragma unroll
+            for (int i = 0; i < 3; i++) col6(r[i], v[i]);
+            if (LG_W4_EXP & 1) { v[0][0] = D(0, 0); v[1][1] = D(1, 1); v[2][2] = D(2, 2); }
+            if (th == 0) {      // positions 0..17
+                *reinterpret_cast<f32x4*>(g0) = (f32x4){v[0][0], v[0][1], v[0][2], v[0][3]};
+                *reinterpret_cast<f32x4*>(g0 + 256) = (f32x4){v[0][4], v[0][5], v[1][0], v[1][1]};
+                *reinterpret_cast<f32x4*>(g0 + 512) = (f32x4){v[1][2], v[1][3], v[1][4], v[1][5]};
+                *reinterpret_cast<f32x4*>(g0 + 768) = (f32x4){v[2][0], v[2][1], v[2][2], v[2][3]};
+                *reinterpret_cast<f32x2*>(g0 + 1024) = (f32x2){v[2][4], v[2][5]};
+            } else {            // positions 18..35
+                *reinterpret_cast<f32x2*>(g0 + 1024 + 2) = (f32x2){v[0][0], v[0][1]};
+                *reinterpret_cast<f32x4*>(g0 + 1280) = (f32x4){v[0][2], v[0][3], v[0][4], v[0][5]};
+                *reinterpret_cast<f32x4*>(g0 + 1536) = (f32x4){v[1][0], v[1][1], v[1][2], v[1][3]};
+                *reinterpret_cast<f32x4*>(g0 + 1792) = (f32x4){v[1][4], v[1][5], v[2][0], v[2][1]};
+                *reinterpret_cast<f32x4*>(g0 + 2048) = (f32x4){v[2][2], v[2][3], v[2][4], v[2][5]};
+            }
+        };
+
+        // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
+        if (!IS_T) {
+            set_input_item(0);
+#pragma unroll
+            for (int j = 0; j < NIN; j++) input_piece(j, 0);
+            input_advance();
+            const float* ablk0 = U4 + (size_t)item_at(0).cob * ABLK;
+#pragma unroll
+            for (int j = 0; j < 9; j++) a_piece(j, ablk0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (IS_T) {
+            f32x4 dl[5];
+            f32x2 dh[5];
+            transform_load(0, dl, dh);
+            transform_store(0, dl, dh);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            if (Q > 1) {
+#pragma unroll
+                for (int j = 0; j < NIN; j++) input_piece(j, 1);
+                input_advance();
+            }
+            if (NSTG == 3 && Q > 2) {   // chunk 2 may stay in flight across the barrier
+#pragma unroll
+                for (int j = 0; j < NIN; j++) input_piece(j, 2);
+                input_advance();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIN) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");
+
+        int q = 0;                                              // chunk counter over all items (stage parity)
 #pragma unroll 1
-        for (int c = 0; c < NC; c++, q++) {
-            const int st = q & 1;
-            const bool more = q + 1 < Q;
-            if (more) issue_a(c + 1 < NC ? cur.cob : cob_next, c + 1 < NC ? c + 1 : 0, st ^ 1);
-            if (q + 2 < Q) input_next(st);                   // stage st: read by the transform of chunk q, one iteration ago
-            // Fragment ring: position group pg uses slot pg % 3, its reads are issued two groups ahead of its MFMAs; every wait
-            // leaves the (up to) 4 fragment reads issued after the awaited pair in flight.  The transform of the next chunk sits between the groups: its LDS
-            // reads are issued first (hipcc drains lgkmcnt before their use: by then their latency has passed behind MFMAs).
-            f32x4 fa[3] = {}, fb[3] = {};
-            const unsigned ap = (unsigned)(size_t)(a_rd + st * ABLK), bp = (unsigned)(size_t)(b_rd + st * VBLK);
-            f32x4 dl[4];
-            f32x2 dh[4];
-            transform_load(row_a, st ^ 1, dl, dh);           // (after the very last chunk: stale bytes into an unused V stage)
+        for (int it_i = 0; it_i < ni; it_i++) {
+            const Item cur = item_at(it_i);
+            const int cob_next = it_i + 1 < ni ? item_at(it_i + 1).cob : cur.cob;
+            f32x4 acc[36];
+#pragma unroll
+            for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int c = 0; c < NC; c++, q++) {
+                const int st = q & 1;                           // A / V stage of this chunk
+                const int in_next = NSTG == 3 ? (q + 1) % 3 : st ^ 1;   // input stage holding chunk q + 1 (transformed now)
+                const int in_free = NSTG == 3 ? q % 3 : st;             // input stage the staging waves refill (chunk q + NSTG)
+                // Fragment ring: position group pg uses slot pg % 3, its reads are issued two groups ahead of its MFMAs; every
+                // wait leaves the (up to) 4 fragment reads issued after the awaited pair in flight.
+                f32x4 fa[3] = {}, fb[3] = {};
+                const unsigned ap = (unsigned)(size_t)(a_rd + st * ABLK), bp = (unsigned)(size_t)(b_rd + st * VBLK);
 #define LG_FRAG(PG) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], ap); lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], bp); }
 #define LG_MM(PG)                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if (!(LG_W4_EXP & 32)) _Pragma("unroll") for (int e = 0; e < 4; e++)                                                 \
         acc[4 * (PG) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[(PG) % 3][e], fb[(PG) % 3][e], acc[4 * (PG) + e], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0)   /* hipcc moves register-only instructions across asm statements, the barrier included */
-            LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
-            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
-            LG_FRAG(3);
-            lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
-            __builtin_amdgcn_sched_barrier(0);
-            transform_store(row_a, st ^ 1, dl, dh);
-            transform_load(row_b, st ^ 1, dl, dh);
-            __builtin_amdgcn_sched_barrier(0);
-            LG_FRAG(4);
-            lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
-            LG_FRAG(5);
-            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
-            LG_FRAG(6);
-            lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
-            LG_FRAG(7);
-            lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
-            __builtin_amdgcn_sched_barrier(0);
-            transform_store(row_b, st ^ 1, dl, dh);
-            __builtin_amdgcn_sched_barrier(0);
-            LG_FRAG(8);
-            lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
-            lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
-            lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+                if (IS_T) {
+                    f32x4 dl[5];
+                    f32x2 dh[5];
+                    transform_load(in_next, dl, dh);             // (after the very last chunk: stale bytes into an unused V stage)
+                    LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
+                    LG_FRAG(3);
+                    lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
+                    transform_store(st ^ 1, dl, dh);             // hipcc drains lgkmcnt here: the loads' latency has passed
+                    __builtin_amdgcn_sched_barrier(0);
+                    LG_FRAG(4);
+                    lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
+                    LG_FRAG(5);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
+                    LG_FRAG(6);
+                    lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
+                    LG_FRAG(7);
+                    lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
+                    LG_FRAG(8);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
+                    lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
+                    lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+                } else {
+                    // the next chunk's U block (9 transfers), then the input NSTG chunks ahead (NIN transfers): three transfers after
+                    // each of the first MFMA groups
+                    const bool more = q + 1 < Q, more2 = q + NSTG < Q;
+                    const float* ablk = U4 + (size_t)(c + 1 < NC ? cur.cob : cob_next) * ABLK + (size_t)(c + 1 < NC ? c + 1 : 0) * NCB * ABLK;
+                    constexpr int NT = 9 + NIN;                  // transfers per chunk and staging wave
+                    auto xfer = [&](int k0, int k1) {            // transfers k0 .. k1 - 1 of the chunk's list: A first, then input
+#pragma unroll
+                        for (int k = k0; k < k1 && k < NT; k++) {
+                            if (k < 9) { if (more) a_piece(k, ablk, st ^ 1); }
+                            else if (more2) input_piece(k - 9, in_free);   // read by the transform of chunk q, one iteration ago
+                        }
+                    };
+                    LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
+                    xfer(0, 3);
+                    LG_FRAG(3);
+                    lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
+                    xfer(3, 6);
+                    LG_FRAG(4);
+                    lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
+                    xfer(6, 9);
+                    LG_FRAG(5);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
+                    xfer(9, 12);
+                    LG_FRAG(6);
+                    lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
+                    xfer(12, NT);
+                    if (more2) input_advance();
+                    LG_FRAG(7);
+                    lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
+                    LG_FRAG(8);
+                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
+                    lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
+                    lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+                }
 #undef LG_FRAG
 #undef LG_MM
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+                // staging waves: the U block of the next chunk (and everything older) has landed; with 3 input stages the NIN
+                // input transfers just issued (the youngest) stay in flight across the barrier
+                if (!IS_T && NSTG == 3 && q + NSTG < Q) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
 
-        // ---- item done: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
-        if (LG_W4_EXP & 64) { if (acc[0][0] == 123.456f) out[t] = acc[1][1] + acc[35][3]; continue; }
-        constexpr int WO = POOL ? WI / 2 : WI;
-        constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
-        constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
-        constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
-        const int etau = 16 * tbw + (lane & 15);
-        const int epb = etau / TPB, etl = etau % TPB;
-        const int n = cur.n0 + epb;
-        const int trg = cur.band * TROWS + etl / TC, tcg = etl % TC;
+            // ---- item done: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
+            constexpr int WO = POOL ? WI / 2 : WI;
+            constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
+            constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
+            constexpr int OO = OUT_HALO ? lg_wp(WO) + 1 : 0;
+            const int etau = 16 * tbw + (lane & 15);
+            const int epb = etau / TPB, etl = etau % TPB;
+            const int n = cur.n0 + epb;
+            const int trg = cur.band * TROWS + etl / TC, tcg = etl % TC;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
-            float s[4][6];
+            for (int r = 0; r < 4; r++) {
+                const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
+                float s[4][6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r],
-                            m5 = acc[30 + j][r];
-                const float t1 = m1 + m2, t2 = m1 - m2, t3 = m3 + m4, t4 = m3 - m4;
-                s[0][j] = m0 + t1 + t3;
-                s[1][j] = fmaf(2.f, t4, t2);
-                s[2][j] = fmaf(4.f, t3, t1);
-                s[3][j] = fmaf(8.f, t4, t2) + m5;
-            }
-            const float bv = bias[co];
-            float y[4][4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
-                y[p][0] = s[p][0] + t1 + t3 + bv;
-                y[p][1] = fmaf(2.f, t4, t2) + bv;
-                y[p][2] = fmaf(4.f, t3, t1) + bv;
-                y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
-            }
-            if (n < N) {
-                float* o = out + ((size_t)n * COUT + co) * OPL + OO;
-                // One vector store per tile row (interior pixels start at an odd column: 4-byte aligned 8 / 16-byte stores,
-                // which the hardware takes): a wave instruction then covers whole 64-128-byte runs of the plane.  Scattered
-                // dword stores (64 lines per instruction, one line per clock in the vector L1) cost 1.9 of 5.3 ms.
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-                if (POOL) {
-#pragma unroll
-                    for (int p = 0; p < 2; p++) {
-                        const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
-                        const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
-                        *reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg) = (f32x2u){v0, v1};
-                    }
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 4; p++)
-                        *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
-                            (f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)};
+                for (int j = 0; j < 6; j++) {
+                    const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r],
+                                m5 = acc[30 + j][r];
+                    const float t1 = m1 + m2, t2 = m1 - m2, t3 = m3 + m4, t4 = m3 - m4;
+                    s[0][j] = m0 + t1 + t3;
+                    s[1][j] = fmaf(2.f, t4, t2);
+                    s[2][j] = fmaf(4.f, t3, t1);
+                    s[3][j] = fmaf(8.f, t4, t2) + m5;
                 }
+                const float bv = bias[co];
+                float y[4][4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
+                    y[p][0] = s[p][0] + t1 + t3 + bv;
+                    y[p][1] = fmaf(2.f, t4, t2) + bv;
+                    y[p][2] = fmaf(4.f, t3, t1) + bv;
+                    y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
+                }
+                if (n < N) {
+                    float* o = out + ((size_t)n * COUT + co) * OPL + OO;
+                    // One vector store per tile row (interior pixels start at an odd column: 4-byte aligned 8 / 16-byte stores,
+                    // which the hardware takes): a wave instruction covers whole 64-128-byte runs of the plane.
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                    if (POOL) {
+#pragma unroll
+                        for (int p = 0; p < 2; p++) {
+                            const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
+                            const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
+                            *reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg) = (f32x2u){v0, v1};
+                        }
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 4; p++)
+                            *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
+                                (f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
             }
-            __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
         }
-    }
+    };
+    if (wave < 4) role(std::true_type{});
+    else role(std::false_type{});
 }
 
 // attention, global average pool, classifier F -> F -> F/2 -> F/4 -> 1 (BN folded).  model.py:30-60,63-84,108-128.
