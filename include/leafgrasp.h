@@ -174,7 +174,8 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
                   float cx, float cy, float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves,
                   int32_t* extrema, void* stream);
 /* The same for B frames per call: labels / depth [B][H][W] DEVICE; stats [B][max_leaves], n_leaves [B], extrema [B][4],
-   status [B] HOST (per-frame lg_status: a frame with more than 64 labels fails alone).  Every pass carries the frame
+   status [B] HOST (per-frame lg_status: a frame with more than 1024 labels fails alone with LG_ERR_UNSUPPORTED; one with more
+   than max_leaves labels with LG_ERR_INVALID and its label count in n_leaves, so the caller can come back with room).  Every pass carries the frame
    in its grid; there is no host round trip between the passes. */
 int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
                         float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,

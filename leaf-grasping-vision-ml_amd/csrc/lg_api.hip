@@ -68,7 +68,8 @@ struct lg_ctx {
     // experiment switches, read ONCE at lg_create (never on the per-call path)
     int opt_subbatch = 0;        // LG_SUBBATCH=n: sub-batch multi-stream pipeline inside lg_select_grasp (0 = off)
     bool opt_trace = false;      // LG_TRACE: per-call timeline on stderr
-    bool opt_no_skip = false;    // LG_NO_SKIP: lg_final_kernel without the constant-tile fast path (dense-path roofline)
+    int opt_no_skip = 0;         // LG_NO_SKIP=1: lg_final_kernel without the constant-tile fast path (dense-path roofline);
+                                 //            =3: also without the wave-level off-leaf shortcut
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
 };
 
@@ -295,7 +296,7 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
     if (const char* e = getenv("LG_SUBBATCH")) h->opt_subbatch = std::max(1, atoi(e));
     h->opt_trace = getenv("LG_TRACE") != nullptr;
-    h->opt_no_skip = getenv("LG_NO_SKIP") != nullptr;
+    if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e));
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
@@ -486,7 +487,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     gaussian1d(a.k1);
-    a.no_skip = h->opt_no_skip ? 1 : 0;
+    a.no_skip = h->opt_no_skip;
     a.nt_stores = h->opt_nt_stores ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
         ProfScope ps(h, "final", s, true);

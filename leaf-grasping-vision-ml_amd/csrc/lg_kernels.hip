@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
             // A leaf covers a few per cent of a frame: when no lane of this wave sits on the mask every plane but
             // flatness is exactly zero (they are all "* mask"), traditional = w_flat * flatness and nothing is
             // valid.  The wave-uniform branch skips the geometry / SDF / isolation arithmetic for those rows.
-            const bool wave_on_mask = a.no_skip || __ballot(mnib != 0) != 0ull;
+            const bool wave_on_mask = (a.no_skip & 2) || __ballot(mnib != 0) != 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int x = x0 + j;

@@ -1,12 +1,18 @@
 // Leaf-selection statistics on gfx950: the per-leaf full-frame passes of
-// OptimalLeafSelector.select_optimal_leaf (scripts/utils/leaf_scorer.py:25-203) in a fixed number of
-// streaming passes over the int16 label image + f32 depth:
-//   * label presence bitmap -> compact slot per id (torch.unique, :32)
-//   * per-slot area, sum x, sum y (int64, exact), sum depth, sum ray length (f64), border flag, first leaf pixel
-//   * per-slot exact median depth by 4x8-bit radix select on order-preserving keys (+1 successor pass for
-//     even counts)  (np.median, :41-47)
-//   * global clutter extrema (:66-71): exact squared Euclidean distance to the nearest leaf pixel
-//     (column scan + per-row monotone-minima divide and conquer), arg-max with first-occurrence ties.
+// OptimalLeafSelector.select_optimal_leaf (scripts/utils/leaf_scorer.py:25-203) as a few streaming passes, B frames per launch:
+//   k_presence_bits  labels once (2 B/px): label presence bitmap -> compact slot per id (torch.unique, :32), the bit mask
+//                    "pixel belongs to some leaf" (1 bit/px) and the first leaf pixel (the field's arg-min, :70)
+//   k_accumulate     labels + depth of the leaf runs: per-slot area, sum x, sum y (int64, exact), sum depth, sum ray length
+//                    (f64), border flag; every leaf pixel is appended to an unordered (slot, depth key) list (8 B per leaf pixel)
+//   k_hist x4        exact median depth (np.median, :41-47) by 4 x 8-bit radix select over THAT list (leaves cover 15-30 % of a
+//                    frame: each pass reads ~1.5 B/px instead of 6), + k_successor for even counts; LDS histograms hold 64 slots,
+//                    frames with more labels (up to 1024) run further slot groups in the grid's z dimension
+//   k_edt_bb         global clutter extrema (:66-71): arg-max of the exact Euclidean distance to the nearest leaf pixel, first
+//                    occurrence, by branch and bound on the bit mask -- the distance field is 1-Lipschitz, so a square cell whose
+//                    centre value + half diagonal stays below the best value found so far cannot hold the maximum.  32-px cells,
+//                    then 16, 8, 4, 2, 1: a few thousand exact point evaluations per frame instead of a full transform (the
+//                    column scan + per-row lower-envelope pass it replaces took 4.2 of the stage's 8.3 ms per 128 frames and
+//                    stays as the fallback for a frame whose survivor list overflows).
 #include "lg_leaf.h"
 
 #include <limits.h>
@@ -16,8 +22,11 @@
 #include <algorithm>
 #include <vector>
 
-#define LGL_MAXL 64          // labels per frame supported by the LDS histograms
+#define LGL_GROUP 64         // slots per LDS histogram group
+#define LGL_MAXL 1024        // distinct labels per frame supported (16 groups)
+#define LGL_ACC_LDS 256      // slots whose sums are aggregated in LDS (beyond: global atomics)
 #define LGL_RUN 16           // consecutive pixels per thread (run-length aggregation before atomics)
+#define LGL_QCAP 65536       // survivor list capacity of the branch-and-bound pass (entries per frame and list)
 
 namespace {
 
@@ -30,57 +39,7 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float(b);
 }
 
-// ---------------------------------------------------------------- presence bitmap of ids 1..32767
-__global__ __launch_bounds__(256) void k_presence(const int16_t* __restrict__ lab, long long n,
-                                                  unsigned long long* __restrict__ pres) {
-    __shared__ unsigned long long s_p[512];
-    lab += (size_t)blockIdx.y * n;     // frame = blockIdx.y
-    pres += (size_t)blockIdx.y * 512;
-    for (int i = threadIdx.x; i < 512; i += 256) s_p[i] = 0;
-    __syncthreads();
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long stride = (long long)gridDim.x * 256;
-    int last = 0;
-    for (; i < n; i += stride) {
-        int id = lab[i];
-        if (id > 0 && id != last) {
-            unsigned long long bit = 1ull << (id & 63);
-            if (!(s_p[id >> 6] & bit)) atomicOr(&s_p[id >> 6], bit);
-            last = id;
-        }
-    }
-    __syncthreads();
-    for (int w = threadIdx.x; w < 512; w += 256)
-        if (s_p[w]) atomicOr(&pres[w], s_p[w]);
-}
-
-// prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1))
-__global__ void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
-    pres += (size_t)blockIdx.x * 512;  // one workgroup per frame
-    pre += (size_t)blockIdx.x * 512;
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int w = 0; w < 512; w++) {
-            pre[w] = acc;
-            acc += __popcll(pres[w]);
-        }
-        nlab[blockIdx.x] = acc;
-    }
-}
-
-__device__ __forceinline__ int slot_of(int id, const unsigned long long* pres, const int* pre) {
-    unsigned long long w = pres[id >> 6];
-    return pre[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull));
-}
-
-struct LeafAcc {  // device accumulators, one per slot
-    unsigned long long area;
-    long long sum_x, sum_y;
-    double sum_depth, sum_ray;
-    int border;
-    int pad;
-};
-
+// ---------------------------------------------------------------- presence bitmap of ids 1..32767 + leaf bit mask
 // The LGL_RUN labels of a run in registers: two 16-byte loads when the row pitch and the base allow it (a wave then reads
 // 2 KB of consecutive labels), element loads otherwise.  Returns false for a run without a positive label -- most runs of a
 // frame are background, and they end here after one 32-byte read.
@@ -123,69 +82,199 @@ __device__ inline bool run_vec_ok(const int16_t* lab, const float* depth, int W)
     return (W % LGL_RUN) == 0 && (reinterpret_cast<uintptr_t>(lab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0;
 }
 
-// ---------------------------------------------------------------- per-slot sums
-__global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ lab, const float* __restrict__ depth,
-                                                    int H, int W, const unsigned long long* __restrict__ pres,
-                                                    const int* __restrict__ pre, float cx, float cy, float f,
-                                                    LeafAcc* __restrict__ acc, unsigned long long* __restrict__ first_leaf) {
-    __shared__ LeafAcc s_acc[LGL_MAXL];
+
+// one thread per 16-pixel run: presence bits of its labels, its 16 mask bits; four lanes assemble a 64-bit word of the mask
+// (rows are padded to whole words: WW = ceil(W / 64), 4 WW runs per row, bits past W are 0)
+__global__ __launch_bounds__(256) void k_presence_bits(const int16_t* __restrict__ lab, const float* __restrict__ depth_unused,
+                                                       int H, int W, int WW, unsigned long long* __restrict__ pres,
+                                                       unsigned long long* __restrict__ bits,
+                                                       unsigned long long* __restrict__ first_leaf) {
+    __shared__ unsigned long long s_p[512];
     __shared__ unsigned long long s_first;
     {
         const size_t fr = blockIdx.y;
-        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; acc += fr * LGL_MAXL; first_leaf += fr;
+        lab += fr * H * W; pres += fr * 512; bits += fr * H * WW; first_leaf += fr;
     }
-    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) {
+    for (int i = threadIdx.x; i < 512; i += 256) s_p[i] = 0;
+    if (threadIdx.x == 0) s_first = ~0ull;
+    __syncthreads();
+    const int rpr = 4 * WW;                               // runs per padded row
+    const long long nruns = (long long)H * rpr;           // a multiple of 4: the four lanes of a word stay together
+    const bool vec = (W % LGL_RUN) == 0 && (reinterpret_cast<uintptr_t>(lab) & 15u) == 0;
+    for (long long r0 = (long long)blockIdx.x * 256; r0 < nruns; r0 += (long long)gridDim.x * 256) {
+        const long long r = r0 + threadIdx.x;
+        unsigned piece = 0;
+        int y = 0, x0 = 0;
+        if (r < nruns) {
+            y = (int)(r / rpr); x0 = (int)(r % rpr) * LGL_RUN;
+            if (x0 < W) {
+                const int x1 = min(x0 + LGL_RUN, W);
+                int16_t ids[LGL_RUN];
+                if (load_run(lab, W, y, x0, x1, vec, ids)) {
+                    int last = 0;
+#pragma unroll
+                    for (int k = 0; k < LGL_RUN; k++) {
+                        const int id = ids[k];
+                        if (id > 0) {
+                            piece |= 1u << k;
+                            if (id != last) {
+                                const unsigned long long bit = 1ull << (id & 63);
+                                if (!(s_p[id >> 6] & bit)) atomicOr(&s_p[id >> 6], bit);
+                                last = id;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // word = pieces of lanes 4q .. 4q+3 (quad exchange)
+        const unsigned p1 = __shfl_down(piece, 1, 64), p2 = __shfl_down(piece, 2, 64), p3 = __shfl_down(piece, 3, 64);
+        if ((threadIdx.x & 3) == 0 && r < nruns) {
+            const unsigned long long word = (unsigned long long)piece | ((unsigned long long)p1 << 16) | ((unsigned long long)p2 << 32) |
+                                            ((unsigned long long)p3 << 48);
+            bits[(size_t)y * WW + (x0 >> 6)] = word;
+            if (word) atomicMin(&s_first, (unsigned long long)y * W + x0 + __builtin_ctzll(word));
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < 512; w += 256)
+        if (s_p[w]) atomicOr(&pres[w], s_p[w]);
+    if (threadIdx.x == 0 && s_first != ~0ull) atomicMin(first_leaf, s_first);
+}
+
+// prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1))
+__global__ void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
+    pres += (size_t)blockIdx.x * 512;  // one workgroup per frame
+    pre += (size_t)blockIdx.x * 512;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < 512; w++) {
+            pre[w] = acc;
+            acc += __popcll(pres[w]);
+        }
+        nlab[blockIdx.x] = acc;
+    }
+}
+
+__device__ __forceinline__ int slot_of(int id, const unsigned long long* pres, const int* pre) {
+    unsigned long long w = pres[id >> 6];
+    return pre[id >> 6] + __popcll(w & ((1ull << (id & 63)) - 1ull));
+}
+
+struct LeafAcc {  // device accumulators, one per slot
+    unsigned long long area;
+    long long sum_x, sum_y;
+    double sum_depth, sum_ray;
+    int border;
+    int pad;
+};
+
+
+// ---------------------------------------------------------------- per-slot sums + the (slot, key) list of the leaf pixels
+__global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ lab, const float* __restrict__ depth,
+                                                    int H, int W, const unsigned long long* __restrict__ pres,
+                                                    const int* __restrict__ pre, float cx, float cy, float f,
+                                                    LeafAcc* __restrict__ acc, unsigned long long* __restrict__ comp,
+                                                    unsigned int* __restrict__ comp_n, size_t comp_stride, unsigned int segcap) {
+    __shared__ LeafAcc s_acc[LGL_ACC_LDS];
+    __shared__ unsigned int s_cnt;                          // entries of this workgroup's list segment so far
+    {
+        const size_t fr = blockIdx.y;
+        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; acc += fr * LGL_MAXL;
+        // the list of a frame is one segment per workgroup (capacity = the pixels the workgroup can meet): space is reserved
+        // with an LDS atomic per wave and step, the segment's length is written once at the end -- no global atomics
+        comp += fr * comp_stride + (size_t)blockIdx.x * segcap; comp_n += fr * gridDim.x + blockIdx.x;
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    for (int i = threadIdx.x; i < LGL_ACC_LDS; i += 256) {
         s_acc[i].area = 0; s_acc[i].sum_x = 0; s_acc[i].sum_y = 0;
         s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0;
     }
-    if (threadIdx.x == 0) s_first = ~0ull;
     __syncthreads();
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
     const long long nruns = (long long)H * runs_per_row;
     const double f2 = (double)f * (double)f;
     const bool vec = run_vec_ok(lab, depth, W);
-    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
-        const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
-        const int x1 = min(x0 + LGL_RUN, W);
+    const int lane = threadIdx.x & 63;
+    for (long long r0 = (long long)blockIdx.x * 256; r0 < nruns; r0 += (long long)gridDim.x * 256) {
+        const long long r = r0 + threadIdx.x;
         int16_t ids[LGL_RUN];
-        if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
         float dv[LGL_RUN];
-        load_run_depth(depth, W, y, x0, x1, vec, dv);
-        int cur = 0;
+        int y = 0, x0 = 0, x1 = 0;
+        bool any = false;
+        if (r < nruns) {
+            y = (int)(r / runs_per_row); x0 = (int)(r % runs_per_row) * LGL_RUN;
+            x1 = min(x0 + LGL_RUN, W);
+            any = load_run(lab, W, y, x0, x1, vec, ids);
+        }
+        int cnt = 0;
+        if (any) {
+            load_run_depth(depth, W, y, x0, x1, vec, dv);
+#pragma unroll
+            for (int k = 0; k < LGL_RUN; k++) cnt += ids[k] > 0;
+        }
+        // list positions: exclusive prefix of the lanes' counts + one atomic per wave (the list is unordered: a median only
+        // needs the multiset)
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;                            // wave-uniform: no leaf pixel in these 1024 pixels
+        unsigned base = 0;
+        if (lane == 63) base = atomicAdd(&s_cnt, (unsigned)total);
+        base = __shfl(base, 63, 64);
+        if (!any) continue;
+        unsigned long long* dst = comp + base + (incl - cnt);
+        int cur = 0, cur_slot = 0;
         unsigned long long a = 0; long long sx = 0; double sd = 0.0, sr = 0.0; int bd = 0;
         const double dy = (double)y - (double)cy;
+        auto flush = [&]() {
+            if (cur > 0 && a) {
+                const int s = cur_slot;
+                if (s < LGL_ACC_LDS) {
+                    atomicAdd(&s_acc[s].area, a);
+                    atomicAdd((unsigned long long*)&s_acc[s].sum_x, (unsigned long long)sx);
+                    atomicAdd((unsigned long long*)&s_acc[s].sum_y, (unsigned long long)((long long)a * y));
+                    atomicAdd(&s_acc[s].sum_depth, sd);
+                    atomicAdd(&s_acc[s].sum_ray, sr);
+                    if (bd) atomicOr(&s_acc[s].border, 1);
+                } else if (s < LGL_MAXL) {
+                    atomicAdd(&acc[s].area, a);
+                    atomicAdd((unsigned long long*)&acc[s].sum_x, (unsigned long long)sx);
+                    atomicAdd((unsigned long long*)&acc[s].sum_y, (unsigned long long)((long long)a * y));
+                    atomicAdd(&acc[s].sum_depth, sd);
+                    atomicAdd(&acc[s].sum_ray, sr);
+                    if (bd) atomicOr(&acc[s].border, 1);
+                }
+            }
+        };
 #pragma unroll
-        for (int k = 0; k <= LGL_RUN; k++) {
+        for (int k = 0; k < LGL_RUN; k++) {
             const int x = x0 + k;
-            int id = (k < LGL_RUN) ? (int)ids[k < LGL_RUN ? k : 0] : 0;   // k == LGL_RUN: flush (labels past x1 are 0)
+            int id = (int)ids[k];
             if (id < 0) id = 0;
             if (id != cur) {
-                if (cur > 0 && a) {
-                    int s = slot_of(cur, pres, pre);
-                    if (s < LGL_MAXL) {
-                        atomicAdd(&s_acc[s].area, a);
-                        atomicAdd((unsigned long long*)&s_acc[s].sum_x, (unsigned long long)sx);
-                        atomicAdd((unsigned long long*)&s_acc[s].sum_y, (unsigned long long)((long long)a * y));
-                        atomicAdd(&s_acc[s].sum_depth, sd);
-                        atomicAdd(&s_acc[s].sum_ray, sr);
-                        if (bd) atomicOr(&s_acc[s].border, 1);
-                    }
-                }
+                flush();
                 cur = id; a = 0; sx = 0; sd = 0.0; sr = 0.0; bd = 0;
+                if (id > 0) cur_slot = slot_of(id, pres, pre);
             }
             if (id > 0) {
-                if (a == 0) atomicMin(&s_first, (unsigned long long)y * W + x);
                 a++;
                 sx += x;
-                sd += (double)dv[k < LGL_RUN ? k : 0];
+                sd += (double)dv[k];
                 const double dx = (double)x - (double)cx;
                 sr += sqrt(dx * dx + dy * dy + f2);
                 bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
+                *dst++ = ((unsigned long long)(unsigned)cur_slot << 32) | f2key(dv[k]);
             }
         }
+        flush();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) {
+    for (int i = threadIdx.x; i < LGL_ACC_LDS; i += 256) {
         if (s_acc[i].area) {
             atomicAdd(&acc[i].area, s_acc[i].area);
             atomicAdd((unsigned long long*)&acc[i].sum_x, (unsigned long long)s_acc[i].sum_x);
@@ -195,21 +284,21 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
             if (s_acc[i].border) atomicOr(&acc[i].border, 1);
         }
     }
-    if (threadIdx.x == 0 && s_first != ~0ull) atomicMin(first_leaf, s_first);
+    if (threadIdx.x == 0) *comp_n = s_cnt;
 }
 
-// ---------------------------------------------------------------- radix select (median)
+// ---------------------------------------------------------------- radix select (median) over the (slot, key) list
 struct SelState {       // per slot
     uint32_t prefix;    // key bits fixed so far (high bits)
     uint32_t rank;      // remaining 0-based rank inside the current prefix bucket
-    uint32_t n_le;      // (after the last pass) number of elements <= selected key
+    uint32_t n_le;      // (after the last pass) number of elements equal to the key ranked ABOVE the selected one
     uint32_t key;       // selected key (after the last pass)
 };
 
-// median ranks from the per-slot areas (lower median index), one workgroup per frame
+// median ranks from the per-slot areas (lower median index); grid (LGL_MAXL / 256, B)
 __global__ void k_seed(const LeafAcc* __restrict__ acc, SelState* __restrict__ st) {
-    const size_t fr = blockIdx.x;
-    const int i = threadIdx.x;
+    const size_t fr = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= LGL_MAXL) return;
     const unsigned long long a = acc[fr * LGL_MAXL + i].area;
     SelState z;
@@ -218,68 +307,63 @@ __global__ void k_seed(const LeafAcc* __restrict__ acc, SelState* __restrict__ s
     st[fr * LGL_MAXL + i] = z;
 }
 
-// histogram of digit `pass` (3 = most significant byte) among elements whose higher bytes match the prefix
-__global__ __launch_bounds__(256) void k_hist(const int16_t* __restrict__ lab, const float* __restrict__ depth, int H, int W,
-                                              const unsigned long long* __restrict__ pres, const int* __restrict__ pre,
+// histogram of digit `pass` (3 = most significant byte) among the list entries of slot group blockIdx.z whose higher bytes
+// match their slot's prefix
+__global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restrict__ comp, const unsigned int* __restrict__ comp_n,
+                                              size_t comp_stride, unsigned int segcap, const int* __restrict__ nlab,
                                               const SelState* __restrict__ st, int pass, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_h[LGL_MAXL * 256];
-    {
-        const size_t fr = blockIdx.y;
-        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; st += fr * LGL_MAXL;
-        hist += fr * LGL_MAXL * 256;
-    }
-    for (int i = threadIdx.x; i < LGL_MAXL * 256; i += 256) s_h[i] = 0;
-    __syncthreads();
+    __shared__ uint32_t s_h[LGL_GROUP * 256];
+    __shared__ uint32_t s_prefix[LGL_GROUP];
+    const size_t fr = blockIdx.y;
+    comp += fr * comp_stride + (size_t)blockIdx.x * segcap;   // workgroup x reads the segment k_accumulate's workgroup x wrote
+    const unsigned n = comp_n[fr * gridDim.x + blockIdx.x];
+    const int nl = min(nlab[fr], LGL_MAXL);
     const int shift = 8 * pass;
     const uint32_t himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
-    const bool vec = run_vec_ok(lab, depth, W);
-    const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
-    const long long nruns = (long long)H * runs_per_row;
-    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nruns; r += (long long)gridDim.x * 256) {
-        const int y = (int)(r / runs_per_row), x0 = (int)(r % runs_per_row) * LGL_RUN;
-        const int x1 = min(x0 + LGL_RUN, W);
-        int16_t ids[LGL_RUN];
-        if (!load_run(lab, W, y, x0, x1, vec, ids)) continue;
-        float dv[LGL_RUN];
-        load_run_depth(depth, W, y, x0, x1, vec, dv);
-        int cur_id = 0, cur_slot = -1, cur_bin = -1;
-        uint32_t cnt = 0, cur_prefix = 0;
-#pragma unroll
-        for (int k = 0; k < LGL_RUN; k++) {
-            int id = (int)ids[k];
-            if (id <= 0) continue;
-            if (id != cur_id) {
-                if (cnt) { atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt); cnt = 0; }
-                cur_id = id;
-                cur_slot = slot_of(id, pres, pre);
-                cur_bin = -1;
-                if (cur_slot < LGL_MAXL) cur_prefix = st[cur_slot].prefix;
+    const int lane = threadIdx.x & 63;
+    // slot groups of 64 (the LDS histogram's size); a frame has one unless it carries more than 64 labels
+    for (int g = 0; g * LGL_GROUP < nl; g++) {
+        const int nsl = min(LGL_GROUP, nl - g * LGL_GROUP);
+        const SelState* stg = st + fr * LGL_MAXL + g * LGL_GROUP;
+        uint32_t* histg = hist + (fr * LGL_MAXL + (size_t)g * LGL_GROUP) * 256;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsl * 256; i += 256) s_h[i] = 0;
+        if (threadIdx.x < nsl) s_prefix[threadIdx.x] = stg[threadIdx.x].prefix;
+        __syncthreads();
+        // One entry per lane and load (512 contiguous bytes per wave instruction).  The pixels of a run sit next to each other
+        // in the list and the depths of a leaf share their high bytes, so neighbouring lanes mostly hit the SAME (slot, bin):
+        // each maximal group of equal neighbours inside the wave becomes one LDS atomic of its first lane (ballot of the heads).
+        for (unsigned i0 = 0; i0 < n; i0 += 256) {
+            const unsigned i = i0 + threadIdx.x;
+            int idx = -1;
+            if (i < n) {
+                const unsigned long long e = comp[i];
+                const int slot = (int)(e >> 32) - g * LGL_GROUP;
+                const uint32_t key = (uint32_t)e;
+                if ((unsigned)slot < (unsigned)nsl && (key & himask) == (s_prefix[slot] & himask)) idx = slot * 256 + (int)((key >> shift) & 0xFFu);
             }
-            if (cur_slot >= LGL_MAXL) continue;
-            const uint32_t key = f2key(dv[k]);
-            if ((key & himask) != (cur_prefix & himask)) continue;
-            const int bin = (int)((key >> shift) & 0xFFu);
-            if (bin != cur_bin) {
-                if (cnt) atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt);
-                cnt = 0;
-                cur_bin = bin;
+            const int prev = __shfl_up(idx, 1, 64);
+            const bool head = lane == 0 || idx != prev;
+            const unsigned long long hm = __ballot(head);
+            if (head && idx >= 0) {
+                const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
+                const int len = later ? __builtin_ctzll(later) + 1 : 64 - lane;
+                atomicAdd(&s_h[idx], (uint32_t)len);
             }
-            cnt++;
         }
-        if (cnt) atomicAdd(&s_h[cur_slot * 256 + cur_bin], cnt);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsl * 256; i += 256)
+            if (s_h[i]) atomicAdd(&histg[i], s_h[i]);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < LGL_MAXL * 256; i += 256)
-        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
 
-// pick the bin holding the wanted rank, descend; one thread per slot
-__global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, int pass, int nslots_max) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslots_max) return;
+// pick the bin holding the wanted rank, descend; one thread per slot; grid (LGL_MAXL / 64, B)
+__global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, const int* __restrict__ nlab, int pass) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nlab[blockIdx.y] || s >= LGL_MAXL) return;
     st += (size_t)blockIdx.y * LGL_MAXL;
     hist += (size_t)blockIdx.y * LGL_MAXL * 256;
-    uint32_t* h = hist + s * 256;
+    uint32_t* h = hist + (size_t)s * 256;
     uint32_t rank = st[s].rank, accum = 0;
     int bin = 255;
     for (int b = 0; b < 256; b++) {
@@ -294,36 +378,336 @@ __global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist,
         st[s].key = st[s].prefix;
         st[s].n_le = inbin - (rank - accum) - 1;  // elements equal to the key ranked ABOVE the selected one
     }
-    for (int b = 0; b < 256; b++) h[b] = 0;  // ready for the next pass
+    for (int b = 0; b < 256; b++) h[b] = 0;  // the histogram workspace is left clean: no memset per call
 }
 
-// smallest key strictly greater than the selected key, per slot (upper median for even counts)
-__global__ __launch_bounds__(256) void k_successor(const int16_t* __restrict__ lab, const float* __restrict__ depth, int H,
-                                                   int W, const unsigned long long* __restrict__ pres,
-                                                   const int* __restrict__ pre, const SelState* __restrict__ st,
-                                                   uint32_t* __restrict__ succ) {
-    __shared__ uint32_t s_m[LGL_MAXL];
+// smallest key strictly greater than the selected key, per slot (upper median for even counts); all slots in one pass
+__global__ __launch_bounds__(256) void k_successor(const unsigned long long* __restrict__ comp, const unsigned int* __restrict__ comp_n,
+                                                   size_t comp_stride, unsigned int segcap, const int* __restrict__ nlab,
+                                                   const SelState* __restrict__ st, uint32_t* __restrict__ succ) {
+    __shared__ uint32_t s_key[LGL_MAXL], s_min[LGL_MAXL];
+    const size_t fr = blockIdx.y;
+    comp += fr * comp_stride + (size_t)blockIdx.x * segcap; st += fr * LGL_MAXL; succ += fr * LGL_MAXL;
+    const unsigned n = comp_n[fr * gridDim.x + blockIdx.x];
+    const int nl = min(nlab[fr], LGL_MAXL);
+    for (int i = threadIdx.x; i < nl; i += 256) { s_key[i] = st[i].key; s_min[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long e = comp[i];
+        const int s = (int)(e >> 32);
+        const uint32_t key = (uint32_t)e;
+        if (s < nl && key > s_key[s] && key < s_min[s]) atomicMin(&s_min[s], key);   // (plain pre-test: most elements fail it)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += 256)
+        if (s_min[i] != 0xFFFFFFFFu) atomicMin(&succ[i], s_min[i]);
+}
+
+// ---------------------------------------------------------------- exact EDT arg-max by branch and bound on the bit mask
+// Exact squared distance from (y, x) to the nearest set bit, given that it is <= ub2 (0xFFFFFFFF when nothing is known).
+// One WAVE per point: the 64 lanes take 64 rows at a time (first the 64 rows around y, then 64 more above and 64 more below,
+// ...), each lane finds the set bit of its row nearest to x that could still beat the best value, a wave minimum closes
+// the round.  All lanes return the same value.  (One thread per point made every step a dependent L2 round trip: 30 ms per
+// frame.)
+// lo2: every pixel closer than sqrt(lo2) is known to be background (a parent cell's value minus the centres' distance): the
+//      words of a row that lie inside that disk are not read.  need2: the caller only cares about values >= need2 (a cell
+//      whose bound cannot reach the best value is dropped whatever its exact value): the search stops once it is below.
+__device__ inline uint32_t edt_point_wave(const unsigned long long* __restrict__ bits, int H, int W, int WW, int y, int x,
+                                          uint32_t ub2, uint32_t lo2, uint32_t need2, int lane) {
+    unsigned long long best = (unsigned long long)ub2 + 1ull;   // search for d2 < best
+    const int w0 = x >> 6, b = x & 63;
+    auto row_probe = [&](int yy) -> unsigned long long {        // best d2 of row yy below `best`, or ~0
+        if (yy < 0 || yy >= H) return ~0ull;
+        const long long dyl = (long long)yy - y;
+        const unsigned long long dy2 = (unsigned long long)(dyl * dyl);
+        if (dy2 >= best) return ~0ull;
+        const unsigned long long* row = bits + (size_t)yy * WW;
+        unsigned long long lim = best - dy2;                    // need dx^2 < lim
+        // known-empty disk: in this row no set bit has |dx| < dxe
+        long long dxe = 0;
+        if ((unsigned long long)lo2 > dy2) dxe = (long long)sqrt((double)((unsigned long long)lo2 - dy2));   // floor: conservative
+        long long dl = -1, dr = -1;
+        int kl = 1, kr = 1;                                     // first neighbour word worth reading on each side
+        if (dxe > (b > 63 - b ? b : 63 - b)) {                  // the centre word lies inside the empty disk
+            // word w0 - k spans dx in [b + 1 + 64 (k - 1), b + 64 k], word w0 + k spans [64 k - b, 64 k + 63 - b]: a word whose
+            // farthest bit is still inside the disk holds no set bit
+            const long long nl_ = dxe - b, nr_ = dxe - 63 + b;
+            kl = nl_ <= 64 ? 1 : (int)((nl_ + 63) / 64);
+            kr = nr_ <= 64 ? 1 : (int)((nr_ + 63) / 64);
+        } else {
+            const unsigned long long wc = row[w0];
+            const unsigned long long ml = wc & (b == 63 ? ~0ull : ((2ull << b) - 1ull));   // bits <= b
+            const unsigned long long mr = wc & (~0ull << b);                               // bits >= b
+            if (ml) dl = b - (63 - __builtin_clzll(ml));
+            if (mr) dr = __builtin_ctzll(mr) - b;
+            if (dl >= 0) lim = min(lim, (unsigned long long)(dl * dl) + 1ull);
+            if (dr >= 0) lim = min(lim, (unsigned long long)(dr * dr) + 1ull);
+        }
+        for (int k = min(kl, kr); (dl < 0 || dr < 0); k++) {
+            const long long minl = (long long)b + 1 + 64ll * (k - 1), minr = 64ll * k - b;   // smallest dx of a hit in word w0 -/+ k
+            const bool canl = dl < 0 && k >= kl && w0 - k >= 0 && (unsigned long long)(minl * minl) < lim;
+            const bool canr = dr < 0 && k >= kr && w0 + k < WW && (unsigned long long)(minr * minr) < lim;
+            if (!canl && !canr && ((dl < 0 && k < kl) || (dr < 0 && k < kr))) continue;   // still inside the empty disk on one side
+            if (!canl && !canr) break;
+            if (canl) {
+                const unsigned long long w = row[w0 - k];
+                if (w) { dl = x - ((w0 - k) * 64 + (63 - __builtin_clzll(w))); lim = min(lim, (unsigned long long)(dl * dl) + 1ull); }
+            }
+            if (canr) {
+                const unsigned long long w = row[w0 + k];
+                if (w) { dr = (w0 + k) * 64 + __builtin_ctzll(w) - x; lim = min(lim, (unsigned long long)(dr * dr) + 1ull); }
+            }
+        }
+        long long dx = -1;
+        if (dl >= 0) dx = dl;
+        if (dr >= 0 && (dx < 0 || dr < dx)) dx = dr;
+        return dx >= 0 ? (unsigned long long)(dx * dx) + dy2 : ~0ull;
+    };
+    auto wave_min = [&](unsigned long long v) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long u = __shfl_xor(v, o, 64);
+            v = u < v ? u : v;
+        }
+        return v;
+    };
     {
-        const size_t fr = blockIdx.y;
-        lab += fr * H * W; depth += fr * H * W; pres += fr * 512; pre += fr * 512; st += fr * LGL_MAXL; succ += fr * LGL_MAXL;
+        const unsigned long long v = wave_min(row_probe(y - 32 + lane));
+        if (v < best) best = v;
     }
-    for (int i = threadIdx.x; i < LGL_MAXL; i += 256) s_m[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    const long long n = (long long)H * W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        int id = lab[i];
-        if (id <= 0) continue;
-        int s = slot_of(id, pres, pre);
-        if (s >= LGL_MAXL) continue;
-        uint32_t key = f2key(depth[i]);
-        if (key > st[s].key && key < s_m[s]) atomicMin(&s_m[s], key);
+    for (int m = 1;; m++) {
+        const long long near = 32 + 64ll * (m - 1);             // smallest |dy| of this round's rows
+        if ((unsigned long long)(near * near) >= best) break;
+        if (best < (unsigned long long)need2) break;            // already below what the caller cares about
+        if (y - near < 0 && y + near >= H) break;               // both chunks outside the image from here on
+        unsigned long long v = row_probe(y - 32 - 64 * m + lane);
+        const unsigned long long v2 = row_probe(y + 32 + 64 * (m - 1) + lane);
+        v = wave_min(v2 < v ? v2 : v);
+        if (v < best) best = v;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < LGL_MAXL; i += 256)
-        if (s_m[i] != 0xFFFFFFFFu) atomicMin(&succ[i], s_m[i]);
+    return best > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)best;
 }
 
-// ---------------------------------------------------------------- exact EDT extrema
+// One 1024-thread workgroup (16 waves, one point per wave at a time) per frame.  out: ((u64)D2 << 32) | (0xFFFFFFFF - flat
+// index) of the first farthest background pixel, 0 when the frame has no leaf pixel or no background pixel; flag = 1 when a
+// survivor list overflowed (the caller runs the fallback)
+#define LGL_BB_T 1024
+__global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* __restrict__ bits, int H, int W, int WW,
+                                                     unsigned long long* __restrict__ qa, unsigned long long* __restrict__ qb,
+                                                     unsigned long long* __restrict__ out, int* __restrict__ flag) {
+    __shared__ unsigned int s_lb2, s_na, s_nb, s_any, s_ovf;
+    __shared__ unsigned long long s_res;
+    const int fr = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NW = LGL_BB_T / 64;
+    bits += (size_t)fr * H * WW;
+    qa += (size_t)fr * LGL_QCAP; qb += (size_t)fr * LGL_QCAP;
+    if (t == 0) { s_lb2 = 0; s_na = 0; s_nb = 0; s_any = 0; s_ovf = 0; s_res = 0; }
+    __syncthreads();
+    {   // any leaf pixel at all?
+        unsigned any = 0;
+        for (long long i = t; i < (long long)H * WW; i += LGL_BB_T) any |= bits[i] != 0ull;
+        if (any) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) { if (t == 0) { out[fr] = 0; flag[fr] = 0; } return; }
+    // entry: d2 (32) | y0 (16) | x0 (16) of a cell; level 0: cells of S x S pixels
+    int S = 64;
+    while (((H + S - 1) / S) * ((W + S - 1) / S) > 8192) S *= 2;
+    auto centre = [&](int y0, int x0, int s, int& cy, int& cx, double& rad) {
+        const int y1 = min(y0 + s, H) - 1, x1 = min(x0 + s, W) - 1;      // last pixel of the cell inside the image
+        cy = min(y0 + s / 2, y1); cx = min(x0 + s / 2, x1);
+        const int ry = max(cy - y0, y1 - cy), rx = max(cx - x0, x1 - cx);
+        rad = sqrt((double)(ry * ry + rx * rx));
+    };
+    const int ny = (H + S - 1) / S, nx = (W + S - 1) / S;
+    // Level 0.  (1) occupancy of the cells (any leaf pixel inside).  (2) every 4th cell in both directions exactly -> a first
+    // best value.  (3) the others: a cell next to occupied cells cannot hold the maximum of a frame whose best value is
+    // hundreds of pixels -- its centre is at most (distance to the farthest corner of the nearest occupied cell) from a leaf
+    // pixel; only cells whose bound from that survives are evaluated, and their search may stop as soon as the cell cannot
+    // reach the best value (the list keeps such a cell's inexact, but low enough, value).
+    __shared__ unsigned char s_occ[8192];
+    for (int c = t; c < ny * nx; c += LGL_BB_T) {
+        const int y0 = (c / nx) * S, x0 = (c % nx) * S;
+        const int y1 = min(y0 + S, H), x1 = min(x0 + S, W);
+        unsigned long long any = 0;
+        for (int yy = y0; yy < y1 && !any; yy++)
+            for (int wq = x0 >> 6; wq <= (x1 - 1) >> 6; wq++) {
+                unsigned long long wv = bits[(size_t)yy * WW + wq];
+                const int lo_b = max(x0 - wq * 64, 0), hi_b = min(x1 - wq * 64, 64);          // bit range of the cell inside the word
+                wv >>= lo_b;
+                if (hi_b - lo_b < 64) wv &= (1ull << (hi_b - lo_b)) - 1ull;
+                any |= wv;
+            }
+        s_occ[c] = any != 0;
+    }
+    __syncthreads();
+    auto need_of = [&](double rad) -> uint32_t {
+        const double nd = sqrt((double)s_lb2) - rad - 1e-6;
+        return nd <= 0.0 ? 0u : (uint32_t)(nd * nd);
+    };
+    for (int round = 0; round < 2; round++) {
+        for (int c = wave; c < ny * nx; c += NW) {
+            const bool coarse = ((c / nx) & 3) == 0 && ((c % nx) & 3) == 0;
+            if (coarse != (round == 0)) continue;
+            const int y0 = (c / nx) * S, x0 = (c % nx) * S;
+            int cy, cx; double rad;
+            centre(y0, x0, S, cy, cx, rad);
+            uint32_t ub2 = 0xFFFFFFFFu;
+            if (round) {   // upper bound of the centre value from the occupied cells (all lanes: 64 cells per step, wave minimum)
+                unsigned long long m = ~0ull;
+                for (int o = lane; o < ny * nx; o += 64) {
+                    if (!s_occ[o]) continue;
+                    const int oy0 = (o / nx) * S, ox0 = (o % nx) * S;
+                    const int oy1 = min(oy0 + S, H) - 1, ox1 = min(ox0 + S, W) - 1;
+                    const long long dyf = max(abs(cy - oy0), abs(cy - oy1)), dxf = max(abs(cx - ox0), abs(cx - ox1));
+                    const unsigned long long d = (unsigned long long)(dyf * dyf + dxf * dxf);
+                    m = d < m ? d : m;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const unsigned long long u = __shfl_xor(m, o, 64);
+                    m = u < m ? u : m;
+                }
+                ub2 = m >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
+            }
+            uint32_t d2;
+            if (round && sqrt((double)ub2) + rad + 1e-6 < sqrt((double)s_lb2)) d2 = ub2;   // cannot reach the best value: not evaluated
+            else d2 = edt_point_wave(bits, H, W, WW, cy, cx, ub2, 0u, round ? need_of(rad) : 0u, lane);
+            if (lane == 0) {
+                if (!(round && d2 == ub2 && sqrt((double)ub2) + rad + 1e-6 < sqrt((double)s_lb2))) atomicMax(&s_lb2, d2);
+                qb[c] = ((unsigned long long)d2 << 32) | ((unsigned long long)y0 << 16) | (unsigned long long)x0;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) s_nb = ny * nx;
+    __syncthreads();
+    for (;;) {
+        // filter list B (cells of size S with their centre values) into list A: keep a cell iff its bound reaches the best value
+        const unsigned nb = s_nb;
+        const double lb = sqrt((double)s_lb2);
+        for (unsigned i = t; i < nb; i += LGL_BB_T) {
+            const unsigned long long e = qb[i];
+            const int y0 = (int)((e >> 16) & 0xFFFF), x0 = (int)(e & 0xFFFF);
+            int cy, cx; double rad;
+            centre(y0, x0, S, cy, cx, rad);
+            if (sqrt((double)(uint32_t)(e >> 32)) + rad + 1e-6 >= lb) {
+                const unsigned p = atomicAdd(&s_na, 1u);
+                if (p < LGL_QCAP / 4) qa[p] = e; else s_ovf = 1;   // (a quarter: every survivor has four children)
+            }
+        }
+        __syncthreads();
+        if (s_ovf) { if (t == 0) { out[fr] = 0; flag[fr] = 1; } return; }
+        const unsigned na = s_na;
+        if (S == 1) {   // cells are pixels, bounds are exact: the survivors are the farthest pixels; first occurrence wins
+            const uint32_t lb2 = s_lb2;
+            for (unsigned i = t; i < na; i += LGL_BB_T) {
+                const unsigned long long e = qa[i];
+                if ((uint32_t)(e >> 32) == lb2) {
+                    const uint32_t idx = (uint32_t)((e >> 16) & 0xFFFF) * (uint32_t)W + (uint32_t)(e & 0xFFFF);
+                    atomicMax(&s_res, ((unsigned long long)lb2 << 32) | (uint32_t)(0xFFFFFFFFu - idx));
+                }
+            }
+            __syncthreads();
+            if (t == 0) { out[fr] = s_lb2 ? s_res : 0ull; flag[fr] = 0; }
+            return;
+        }
+        __syncthreads();
+        if (t == 0) { s_nb = 0; }
+        __syncthreads();
+        // children of the survivors: exact centre values (bounded by the parent's value + the centres' distance)
+        const int Sc = S / 2;
+        for (unsigned i = wave; i < na * 4; i += NW) {
+            const unsigned long long e = qa[i >> 2];
+            const int py0 = (int)((e >> 16) & 0xFFFF), px0 = (int)(e & 0xFFFF);
+            const int y0 = py0 + ((i >> 1) & 1) * Sc, x0 = px0 + (i & 1) * Sc;
+            if (y0 >= H || x0 >= W) continue;
+            int pcy, pcx, cy, cx; double prad, rad;
+            centre(py0, px0, S, pcy, pcx, prad);
+            centre(y0, x0, Sc, cy, cx, rad);
+            // the parent's value is exact (it survived the filter: it was not cut short): Lipschitz bounds for the child
+            const double pd = sqrt((double)(uint32_t)(e >> 32)), cd = sqrt((double)((cy - pcy) * (cy - pcy) + (cx - pcx) * (cx - pcx)));
+            const double ubd = pd + cd + 1e-6, lod = pd - cd - 1e-6;
+            const double ub2d = ceil(ubd * ubd);
+            const uint32_t ub2 = ub2d >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)ub2d;
+            const uint32_t lo2 = lod <= 1.0 ? 0u : (uint32_t)floor((lod - 1e-6) * (lod - 1e-6));
+            const uint32_t d2 = edt_point_wave(bits, H, W, WW, cy, cx, ub2, lo2, need_of(rad), lane);
+            if (lane == 0) {
+                atomicMax(&s_lb2, d2);
+                const unsigned p = atomicAdd(&s_nb, 1u);
+                qb[p] = ((unsigned long long)d2 << 32) | ((unsigned long long)y0 << 16) | (unsigned long long)x0;   // p < 4 * QCAP / 4
+            }
+        }
+        __syncthreads();
+        if (t == 0) s_na = 0;
+        S = Sc;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- results in their final form, one copy back
+struct LeafHdr { int n_leaves, status, ext[4], bbflag, pad; };
+// one workgroup per frame: lg_leaf_stat of every slot (id from the presence bits, np.median from the selected key / successor)
+// and the frame header (label count, extrema) -> pinned host memory in ONE copy
+__global__ __launch_bounds__(256) void k_pack(const unsigned long long* __restrict__ pres, const int* __restrict__ pre,
+                                              const int* __restrict__ nlab, const LeafAcc* __restrict__ acc,
+                                              const SelState* __restrict__ st, const uint32_t* __restrict__ succ,
+                                              const unsigned long long* __restrict__ first_leaf,
+                                              const unsigned long long* __restrict__ best, const int* __restrict__ bbflag, int W,
+                                              int max_leaves, lg_leaf_stat* __restrict__ out, LeafHdr* __restrict__ hdr) {
+    const size_t fr = blockIdx.x;
+    pres += fr * 512; pre += fr * 512; acc += fr * LGL_MAXL; st += fr * LGL_MAXL; succ += fr * LGL_MAXL;
+    out += fr * (size_t)max_leaves;
+    const int nl = nlab[fr];
+    const int status = nl > LGL_MAXL ? LG_ERR_UNSUPPORTED : (nl > max_leaves ? LG_ERR_INVALID : LG_OK);
+    if (threadIdx.x == 0) {
+        LeafHdr h;
+        h.n_leaves = status == LG_ERR_UNSUPPORTED ? 0 : nl;   // (too small a result array: the count tells the caller how much room it needs)
+        h.status = status;
+        h.ext[0] = h.ext[1] = h.ext[2] = h.ext[3] = 0;
+        h.bbflag = bbflag[fr]; h.pad = 0;
+        const unsigned long long fl = first_leaf[fr], bs = best[fr];
+        if (fl != ~0ull) { h.ext[0] = (int)(fl / (unsigned)W); h.ext[1] = (int)(fl % (unsigned)W); }
+        if (bs != 0) {   // (no leaf / no background pixel: the field is constant -> arg-max index 0)
+            const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(bs & 0xFFFFFFFFull);
+            h.ext[2] = (int)(idx / (unsigned)W); h.ext[3] = (int)(idx % (unsigned)W);
+        }
+        hdr[fr] = h;
+    }
+    if (status != LG_OK) return;
+    for (int slot = threadIdx.x; slot < nl; slot += 256) {
+        // id of the slot: the (slot - pre[w])-th set bit of the presence word w with pre[w] <= slot < pre[w + 1]
+        int lo = 0, hi = 511;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= slot) lo = mid; else hi = mid - 1;
+        }
+        unsigned long long wv = pres[lo];
+        for (int k = slot - pre[lo]; k > 0; k--) wv &= wv - 1;
+        lg_leaf_stat o;
+        o.id = lo * 64 + __builtin_ctzll(wv);
+        o.area = (int32_t)acc[slot].area;
+        o.touches_border = acc[slot].border;
+        o.pad_ = 0;
+        o.sum_x = (double)acc[slot].sum_x;
+        o.sum_y = (double)acc[slot].sum_y;
+        o.sum_depth = acc[slot].sum_depth;
+        o.sum_ray = acc[slot].sum_ray;
+        // np.median: odd n -> middle element; even n -> float32 mean of the two middle elements
+        const float lo_v = key2f(st[slot].key);
+        if (acc[slot].area % 2 == 1) {
+            o.median_depth = lo_v;
+        } else {
+            const float hi_v = (st[slot].n_le > 0) ? lo_v : key2f(succ[slot]);   // duplicates of the key cover the upper index
+            o.median_depth = __fdiv_rn(__fadd_rn(lo_v, hi_v), 2.0f);           // float32 add, then / 2 (np.mean of 2 float32)
+        }
+        o.pad2_ = 0.f;
+        out[slot] = o;
+    }
+}
+
+// ---------------------------------------------------------------- exact EDT extrema, full-transform form (fallback)
 // phase 1: g[y][x] = vertical distance to the nearest leaf pixel of column x (sentinel when none)
 #define LGL_GINF 16384
 __global__ __launch_bounds__(256) void k_coldist(const int16_t* __restrict__ lab, int H, int W, uint16_t* __restrict__ g) {
@@ -474,21 +858,34 @@ struct LgLeafWs {   // every array holds capB frames back to back
     LeafAcc* acc;              // MAXL
     unsigned long long* first_leaf;  // 1
     SelState* st;              // MAXL
-    uint32_t* hist;            // MAXL*256
+    uint32_t* hist;            // MAXL*256, kept all-zero between calls (k_select clears what k_hist fills)
     uint32_t* succ;            // MAXL
     unsigned long long* best;  // 1
-    uint16_t* g;               // H*W
-    unsigned long long* rowbest;  // H
-    size_t g_cap, rb_cap;
+    int* bbflag;               // 1
+    unsigned int* comp_n;      // 256 (one per k_accumulate workgroup)
+    unsigned long long *qa, *qb;  // LGL_QCAP each
+    unsigned long long* bits;  // H * ceil(W/64)
+    unsigned long long* comp;  // H*W  (slot, key) list of the leaf pixels
+    uint16_t* g;               // H*W   (fallback only, allocated on first use)
+    unsigned long long* rowbest;  // H  (fallback only)
+    lg_leaf_stat* d_out;       // [capB][out_cap] results in their final form (device) ...
+    LeafHdr* d_hdr;            // [capB]
+    lg_leaf_stat* h_out;       // ... and their pinned host copies
+    LeafHdr* h_hdr;
+    int out_cap;
+    size_t px_cap, g_cap, rb_cap;
     int capB;
     hipEvent_t ev_in, ev_side; // fences of the side chain (the side stream belongs to the handle)
 };
 
 void lg_leaf_free(LgLeafWs*& w) {
     if (!w) return;
-    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->g, w->rowbest};
+    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->bbflag, w->comp_n,
+                  w->qa, w->qb, w->bits, w->comp, w->g, w->rowbest, w->d_out, w->d_hdr};
     for (void* p : ps)
         if (p) hipFree(p);
+    if (w->h_out) hipHostFree(w->h_out);
+    if (w->h_hdr) hipHostFree(w->h_hdr);
     if (w->ev_in) hipEventDestroy(w->ev_in);
     if (w->ev_side) hipEventDestroy(w->ev_side);
     delete w;
@@ -505,28 +902,51 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
             hipMalloc((void**)&w->nlab, nb * 4) || hipMalloc((void**)&w->acc, nb * sizeof(LeafAcc) * LGL_MAXL) ||
             hipMalloc((void**)&w->first_leaf, nb * 8) || hipMalloc((void**)&w->st, nb * sizeof(SelState) * LGL_MAXL) ||
             hipMalloc((void**)&w->hist, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->succ, nb * 4 * LGL_MAXL) ||
-            hipMalloc((void**)&w->best, nb * 8))
+            hipMalloc((void**)&w->best, nb * 8) || hipMalloc((void**)&w->bbflag, nb * 4) || hipMalloc((void**)&w->comp_n, nb * 4 * 256) ||
+            hipMalloc((void**)&w->qa, nb * 8 * LGL_QCAP) || hipMalloc((void**)&w->qb, nb * 8 * LGL_QCAP) ||
+            hipMemset(w->hist, 0, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->d_hdr, nb * sizeof(LeafHdr)) ||
+            hipHostMalloc((void**)&w->h_hdr, nb * sizeof(LeafHdr)))
             return LG_ERR_NOMEM;
         if (hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) || hipEventCreateWithFlags(&w->ev_side, hipEventDisableTiming))
             return LG_ERR_HIP;
         w->capB = B;
     }
-    size_t need = (size_t)w->capB * H * W;
+    const size_t need = (size_t)w->capB * H * W;
+    if (need > w->px_cap) {
+        if (w->bits) hipFree(w->bits);
+        if (w->comp) hipFree(w->comp);
+        w->bits = w->comp = nullptr;
+        w->px_cap = 0;
+        // (bits: H rows of ceil(W/64) words <= H * W / 8 + H * 8 bytes)
+        // (comp: per frame the segments of up to 256 workgroups, each rounded up to whole 4096-pixel steps)
+        if (hipMalloc((void**)&w->bits, (size_t)w->capB * H * ((W + 63) / 64) * 8) ||
+            hipMalloc((void**)&w->comp, (need + (size_t)w->capB * 256 * 4096 * 2) * 8)) return LG_ERR_NOMEM;
+        w->px_cap = need;
+    }
+    return LG_OK;
+}
+
+// the full-transform pass (column scan + per-row lower envelope) for a batch: only when a frame's branch-and-bound list overflowed
+static int leaf_edt_fallback(LgLeafWs* w, const int16_t* labels, int B, int H, int W, hipStream_t s) {
+    const size_t need = (size_t)w->capB * H * W, need_rb = (size_t)w->capB * H;
     if (need > w->g_cap) {
         if (w->g) hipFree(w->g);
-        w->g = nullptr;
-        w->g_cap = 0;
+        w->g = nullptr; w->g_cap = 0;
         if (hipMalloc((void**)&w->g, need * 2)) return LG_ERR_NOMEM;
         w->g_cap = need;
     }
-    const size_t need_rb = (size_t)w->capB * H;
     if (need_rb > w->rb_cap) {
         if (w->rowbest) hipFree(w->rowbest);
-        w->rowbest = nullptr;
-        w->rb_cap = 0;
+        w->rowbest = nullptr; w->rb_cap = 0;
         if (hipMalloc((void**)&w->rowbest, need_rb * 8)) return LG_ERR_NOMEM;
         w->rb_cap = need_rb;
     }
+    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s, labels, H, W, w->g);
+    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    else hipLaunchKernelGGL(k_rowedt<4096>, dim3(H, B), dim3(64), 0, s, w->g, H, W, w->rowbest);
+    hipLaunchKernelGGL(k_rowbest, dim3(B), dim3(256), 0, s, w->rowbest, H, w->best);
     return LG_OK;
 }
 
@@ -537,112 +957,85 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
                       hipStream_t s, hipStream_t side, std::string* err) {
     int rc = leaf_ws(w, B, H, W);
     if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
-    if (W > 4096) { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
-    const long long n = (long long)H * W;
+    if (W > 4096 || H > 65535) { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
     const size_t nb = (size_t)B;
+    const int WW = (W + 63) / 64;
     // streaming passes: grid-stride workgroups per frame; fewer per frame for large batches (every workgroup ends with a
     // flush of its LDS accumulators / 64 KB histogram into global atomics)
-    const int gx = std::max(16, std::min(256, 2048 / B));   // (one per CU for a single frame: every workgroup of a frame ends
-                                                             //  with atomics on that frame's few accumulator addresses)
+    const int gx = std::max(16, std::min(256, 2048 / B));
     const dim3 grid(gx, B);
+    // list segments: workgroup x of a frame meets at most ceil(runs / (gx * 256)) steps of 256 runs of 16 pixels
+    const long long nruns_acc = (long long)H * ((W + LGL_RUN - 1) / LGL_RUN);
+    const unsigned segcap = (unsigned)((nruns_acc + (long long)gx * 256 - 1) / ((long long)gx * 256)) * 256u * LGL_RUN;
+    const size_t comp_stride = (size_t)segcap * gx;          // <= H * W + gx * 4096 entries per frame
     hipMemsetAsync(w->pres, 0, nb * 512 * 8, s);
     hipMemsetAsync(w->acc, 0, nb * sizeof(LeafAcc) * LGL_MAXL, s);
     hipMemsetAsync(w->first_leaf, 0xFF, nb * 8, s);
-    hipMemsetAsync(w->hist, 0, nb * 4 * LGL_MAXL * 256, s);
     hipMemsetAsync(w->succ, 0xFF, nb * 4 * LGL_MAXL, s);
-    // clutter extrema: independent of the statistics, and like the median chain bound by latency (dependent LDS round trips
-    // there, LDS atomics here) rather than by bandwidth -- the two chains run side by side on two streams
+    hipLaunchKernelGGL(k_presence_bits, grid, dim3(256), 0, s, labels, depth, H, W, WW, w->pres, w->bits, w->first_leaf);
+    // clutter extrema: needs only the bit mask; runs beside the statistics chain on a second stream of the handle
     // (side = one of the handle's own streams: a stream more per process changes how ROCm maps streams to its few hardware
     //  queues -- an extra stream here made an unrelated trainer in the same process 2.5x slower)
     hipStream_t s2 = side ? side : s;
-    hipEventRecord(w->ev_in, s);            // the caller's inputs are ready on s
+    hipEventRecord(w->ev_in, s);
     hipStreamWaitEvent(s2, w->ev_in, 0);
-    hipLaunchKernelGGL(k_coldist, dim3((W + 255) / 256, B), dim3(256), 0, s2, labels, H, W, w->g);
-    if (W <= 512) hipLaunchKernelGGL(k_rowedt<512>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
-    else if (W <= 1024) hipLaunchKernelGGL(k_rowedt<1024>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
-    else if (W <= 2048) hipLaunchKernelGGL(k_rowedt<2048>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
-    else hipLaunchKernelGGL(k_rowedt<4096>, dim3(H, B), dim3(64), 0, s2, w->g, H, W, w->rowbest);
-    hipLaunchKernelGGL(k_rowbest, dim3(B), dim3(256), 0, s2, w->rowbest, H, w->best);
+    hipLaunchKernelGGL(k_edt_bb, dim3(B), dim3(LGL_BB_T), 0, s2, w->bits, H, W, WW, w->qa, w->qb, w->best, w->bbflag);
     hipEventRecord(w->ev_side, s2);
-    hipLaunchKernelGGL(k_presence, grid, dim3(256), 0, s, labels, n, w->pres);
     hipLaunchKernelGGL(k_prefix, dim3(B), dim3(64), 0, s, w->pres, w->pre, w->nlab);
-    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc,
-                       w->first_leaf);
-    // exact medians: ranks from the areas, 4 radix passes, successor for even counts
-    hipLaunchKernelGGL(k_seed, dim3(B), dim3(LGL_MAXL), 0, s, w->acc, w->st);
+    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc, w->comp, w->comp_n, comp_stride, segcap);
+    // exact medians: ranks from the areas, 4 radix passes over the leaf-pixel list, successor for even counts
+    hipLaunchKernelGGL(k_seed, dim3(LGL_MAXL / 256, B), dim3(256), 0, s, w->acc, w->st);
     for (int pass = 3; pass >= 0; pass--) {
-        hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, pass, w->hist);
-        hipLaunchKernelGGL(k_select, dim3(1, B), dim3(LGL_MAXL), 0, s, w->st, w->hist, pass, LGL_MAXL);
+        hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, pass, w->hist);
+        hipLaunchKernelGGL(k_select, dim3(LGL_MAXL / 64, B), dim3(64), 0, s, w->st, w->hist, w->nlab, pass);
     }
-    hipLaunchKernelGGL(k_successor, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, w->st, w->succ);
+    hipLaunchKernelGGL(k_successor, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, w->succ);
     hipStreamWaitEvent(s, w->ev_side, 0);   // join: `best` is read back below
 
-    std::vector<int> nlab(nb);
-    std::vector<LeafAcc> acc(nb * LGL_MAXL);
-    std::vector<unsigned long long> pres(nb * 512), first_leaf(nb), best(nb);
-    std::vector<SelState> st(nb * LGL_MAXL);
-    std::vector<uint32_t> succ(nb * LGL_MAXL);
-    if (hipMemcpyAsync(nlab.data(), w->nlab, nb * 4, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(acc.data(), w->acc, nb * sizeof(LeafAcc) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(pres.data(), w->pres, nb * 512 * 8, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(st.data(), w->st, nb * sizeof(SelState) * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(succ.data(), w->succ, nb * 4 * LGL_MAXL, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(first_leaf.data(), w->first_leaf, nb * 8, hipMemcpyDeviceToHost, s) ||
-        hipMemcpyAsync(best.data(), w->best, nb * 8, hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s) || hipGetLastError()) {
+    // results in their final form: one pack kernel, one copy into pinned memory
+    if (max_leaves > w->out_cap) {
+        if (w->d_out) hipFree(w->d_out);
+        if (w->h_out) hipHostFree(w->h_out);
+        w->d_out = nullptr; w->h_out = nullptr; w->out_cap = 0;
+        const int cap = std::max(max_leaves, 64);
+        if (hipMalloc((void**)&w->d_out, (size_t)w->capB * cap * sizeof(lg_leaf_stat)) ||
+            hipHostMalloc((void**)&w->h_out, (size_t)w->capB * cap * sizeof(lg_leaf_stat))) {
+            *err = "lg_leaf_stats: workspace allocation failed";
+            return LG_ERR_NOMEM;
+        }
+        w->out_cap = cap;
+    }
+    hipLaunchKernelGGL(k_pack, dim3(B), dim3(256), 0, s, w->pres, w->pre, w->nlab, w->acc, w->st, w->succ, w->first_leaf, w->best,
+                       w->bbflag, W, max_leaves, w->d_out, w->d_hdr);
+    if (hipMemcpyAsync(w->h_hdr, w->d_hdr, nb * sizeof(LeafHdr), hipMemcpyDeviceToHost, s) ||
+        hipMemcpyAsync(w->h_out, w->d_out, nb * max_leaves * sizeof(lg_leaf_stat), hipMemcpyDeviceToHost, s) ||
+        hipStreamSynchronize(s) || hipGetLastError()) {
         *err = "lg_leaf_stats: device copy / kernel failed";
         return LG_ERR_HIP;
     }
+    bool any_flag = false;
+    for (int b = 0; b < B; b++) any_flag |= w->h_hdr[b].bbflag != 0;
+    if (any_flag) {   // a survivor list overflowed somewhere: the full-transform pass for the batch, then the headers once more
+        rc = leaf_edt_fallback(w, labels, B, H, W, s);
+        if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
+        hipMemsetAsync(w->bbflag, 0, nb * 4, s);
+        hipLaunchKernelGGL(k_pack, dim3(B), dim3(256), 0, s, w->pres, w->pre, w->nlab, w->acc, w->st, w->succ, w->first_leaf, w->best,
+                           w->bbflag, W, max_leaves, w->d_out, w->d_hdr);
+        if (hipMemcpyAsync(w->h_hdr, w->d_hdr, nb * sizeof(LeafHdr), hipMemcpyDeviceToHost, s) || hipStreamSynchronize(s)) {
+            *err = "lg_leaf_stats: device copy / kernel failed";
+            return LG_ERR_HIP;
+        }
+    }
     int worst = LG_OK;
     for (int b = 0; b < B; b++) {
-        const int nl = nlab[b];
-        lg_leaf_stat* fstats = stats + (size_t)b * max_leaves;
-        int32_t* ext = extrema + 4 * (size_t)b;
-        n_leaves[b] = 0;
-        ext[0] = ext[1] = ext[2] = ext[3] = 0;
-        int fs = LG_OK;
-        if (nl > LGL_MAXL) { *err = "lg_leaf_stats: more than 64 distinct leaf labels in one frame"; fs = LG_ERR_UNSUPPORTED; }
-        else if (nl > max_leaves) { *err = "lg_leaf_stats: stats capacity too small"; fs = LG_ERR_INVALID; }
-        if (status) status[b] = fs;
-        if (fs) { worst = fs; continue; }
-        const LeafAcc* facc = &acc[(size_t)b * LGL_MAXL];
-        const SelState* fst = &st[(size_t)b * LGL_MAXL];
-        const uint32_t* fsucc = &succ[(size_t)b * LGL_MAXL];
-        // ids in ascending order = slots in ascending order
-        int slot = 0;
-        for (int wi = 0; wi < 512 && slot < nl; wi++) {
-            unsigned long long bits = pres[(size_t)b * 512 + wi];
-            while (bits && slot < nl) {
-                int bb = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                lg_leaf_stat& o = fstats[slot];
-                memset(&o, 0, sizeof(o));
-                o.id = wi * 64 + bb;
-                o.area = (int32_t)facc[slot].area;
-                o.touches_border = facc[slot].border;
-                o.sum_x = (double)facc[slot].sum_x;
-                o.sum_y = (double)facc[slot].sum_y;
-                o.sum_depth = facc[slot].sum_depth;
-                o.sum_ray = facc[slot].sum_ray;
-                // np.median: odd n -> middle element; even n -> float32 mean of the two middle elements
-                auto k2f = [](uint32_t k) { uint32_t v = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float fv; memcpy(&fv, &v, 4); return fv; };
-                float lo = k2f(fst[slot].key);
-                if (facc[slot].area % 2 == 1) {
-                    o.median_depth = lo;
-                } else {
-                    float hi = (fst[slot].n_le > 0) ? lo : k2f(fsucc[slot]);  // duplicates of the key cover the upper index
-                    float sum = lo + hi;                                       // float32 add, then /2 (np.mean of 2 float32)
-                    o.median_depth = sum / 2.0f;
-                }
-                slot++;
-            }
-        }
-        n_leaves[b] = nl;
-        // extrema: argmin = first leaf pixel (row-major); argmax = farthest background pixel, first occurrence
-        if (first_leaf[b] != ~0ull) { ext[0] = (int32_t)(first_leaf[b] / W); ext[1] = (int32_t)(first_leaf[b] % W); }
-        if (best[b] != 0) {   // (no background pixel: the field is all zeros -> argmax index 0)
-            uint32_t idx = 0xFFFFFFFFu - (uint32_t)(best[b] & 0xFFFFFFFFull);
-            ext[2] = (int32_t)(idx / W); ext[3] = (int32_t)(idx % W);
-        }
+        const LeafHdr& h = w->h_hdr[b];
+        n_leaves[b] = h.n_leaves;
+        for (int k = 0; k < 4; k++) extrema[4 * (size_t)b + k] = h.ext[k];
+        if (status) status[b] = h.status;
+        if (h.status == LG_ERR_UNSUPPORTED) *err = "lg_leaf_stats: more than 1024 distinct leaf labels in one frame";
+        else if (h.status == LG_ERR_INVALID) *err = "lg_leaf_stats: stats capacity too small";
+        if (h.status) { worst = h.status; continue; }
+        memcpy(stats + (size_t)b * max_leaves, w->h_out + (size_t)b * max_leaves, sizeof(lg_leaf_stat) * (size_t)h.n_leaves);
     }
     return status ? LG_OK : worst;
 }

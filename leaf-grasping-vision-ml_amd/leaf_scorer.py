@@ -17,12 +17,13 @@ import math
 import numpy as np
 import torch
 
-from ._lib import LgLeafStat, check, lib
+from ._lib import LG_ERR_INVALID, LgLeafStat, check, lib
 from ._log import logerr, loginfo, logwarn
 from .grasp_point_selector import _device_index
 
 _VP = C.c_void_p
-_MAX_LEAVES = 64
+_MAX_LEAVES = 64      # result capacity of the first attempt; a frame with more labels (up to 1024) is re-read with room for them
+_MAX_LABELS = 1024    # distinct labels per frame the library handles (lg_leaf.hip: LGL_MAXL)
 # numpy view of lg_leaf_stat (include/leafgrasp.h; ctypes mirror: _lib.LgLeafStat)
 _STAT_DTYPE = np.dtype([("id", "<i4"), ("area", "<i4"), ("touches_border", "<i4"), ("pad_", "<i4"), ("sum_x", "<f8"),
                         ("sum_y", "<f8"), ("sum_depth", "<f8"), ("sum_ray", "<f8"), ("median_depth", "<f4"), ("pad2_", "<f4")])
@@ -90,14 +91,21 @@ class OptimalLeafSelector:
         lab = lab.contiguous()
         dep = torch.as_tensor(depth_tensor).to(self.device, torch.float32).contiguous()
         H, W = lab.shape
-        stats = (LgLeafStat * _MAX_LEAVES)()
-        n = C.c_int(0)
-        ext = (C.c_int32 * 4)()
-        with torch.cuda.device(self.device):
-            check(self._h, lib.lg_leaf_stats(self._h, lab.data_ptr(), dep.data_ptr(), H, W,
-                                             float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
-                                             stats, _MAX_LEAVES, C.byref(n), ext,
-                                             _VP(torch.cuda.current_stream(self.device).cuda_stream)), "lg_leaf_stats")
+        cap = _MAX_LEAVES
+        while True:
+            stats = (LgLeafStat * cap)()
+            n = C.c_int(0)
+            ext = (C.c_int32 * 4)()
+            with torch.cuda.device(self.device):
+                rc = lib.lg_leaf_stats(self._h, lab.data_ptr(), dep.data_ptr(), H, W,
+                                       float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
+                                       stats, cap, C.byref(n), ext,
+                                       _VP(torch.cuda.current_stream(self.device).cuda_stream))
+            if rc == LG_ERR_INVALID and cap < n.value <= _MAX_LABELS:   # more labels than the result array holds: once more
+                cap = n.value
+                continue
+            check(self._h, rc, "lg_leaf_stats")
+            break
         out = []
         for i in range(n.value):
             s = stats[i]
@@ -108,26 +116,33 @@ class OptimalLeafSelector:
 
     def leaf_statistics_batch(self, mask_tensors, depth_tensors):
         """B frames [B,H,W] per call (lg_leaf_stats_batch) -> list of (stats, extrema, (H, W)) or None for a frame the
-        library could not handle (more than 64 labels)."""
+        library could not handle (more than 1024 labels)."""
         lab = torch.as_tensor(mask_tensors).to(self.device)
         if lab.dtype != torch.int16:
             lab = lab.to(torch.int16)
         lab = lab.contiguous()
         dep = torch.as_tensor(depth_tensors).to(self.device, torch.float32).contiguous()
         B, H, W = lab.shape
-        stats = (LgLeafStat * (_MAX_LEAVES * B))()
-        n = (C.c_int * B)()
-        ext = (C.c_int32 * (4 * B))()
-        status = (C.c_int * B)()
-        with torch.cuda.device(self.device):
-            check(self._h, lib.lg_leaf_stats_batch(self._h, lab.data_ptr(), dep.data_ptr(), B, H, W,
-                                                   float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
-                                                   stats, _MAX_LEAVES, n, ext, status,
-                                                   _VP(torch.cuda.current_stream(self.device).cuda_stream)),
-                  "lg_leaf_stats_batch")
+        cap = _MAX_LEAVES
+        while True:
+            stats = (LgLeafStat * (cap * B))()
+            n = (C.c_int * B)()
+            ext = (C.c_int32 * (4 * B))()
+            status = (C.c_int * B)()
+            with torch.cuda.device(self.device):
+                check(self._h, lib.lg_leaf_stats_batch(self._h, lab.data_ptr(), dep.data_ptr(), B, H, W,
+                                                       float(self.camera_cx), float(self.camera_cy), float(self.f_norm),
+                                                       stats, cap, n, ext, status,
+                                                       _VP(torch.cuda.current_stream(self.device).cuda_stream)),
+                      "lg_leaf_stats_batch")
+            need = max([n[b] for b in range(B) if status[b] == LG_ERR_INVALID], default=0)
+            if cap < need <= _MAX_LABELS:       # some frame has more labels than the result rows hold: once more with room
+                cap = need
+                continue
+            break
         # one structured view over the whole result instead of a ctypes attribute read per field (8 fields x ~8 leaves x B
         # frames were 2 of the 3 ms of host time per 128 frames)
-        arr = np.frombuffer(stats, dtype=_STAT_DTYPE).reshape(B, _MAX_LEAVES)
+        arr = np.frombuffer(stats, dtype=_STAT_DTYPE).reshape(B, cap)
         nn, st, ex = np.frombuffer(n, np.int32), np.frombuffer(status, np.int32), np.frombuffer(ext, np.int32).reshape(B, 4).tolist()
         out = []
         for b in range(B):
@@ -160,7 +175,7 @@ class OptimalLeafSelector:
         out, tall = [], []
         for fr in per_frame:
             if fr is None:
-                logerr("Error in leaf selection: unsupported frame (more than 64 labels)")
+                logerr("Error in leaf selection: unsupported frame (more than 1024 labels)")
                 out.append(None)
             else:
                 out.append(self._select_from_statistics(*fr))

@@ -96,6 +96,89 @@ def test_hip_clutter_extrema_vs_restated_fmm(L, shape):
     assert worst_cl <= _FMM_CLUTTER_ABS, worst_cl
 
 
+def test_leaf_many_labels(L):
+    """leaf_scorer.py:32 takes any number of labels (torch.unique).  The LDS histograms of the median pass hold 64 slots; frames
+    with more labels run further slot groups (up to 1024 labels): statistics and medians stay exact, the wrapper re-reads the
+    frame with room for the results."""
+    rng = np.random.default_rng(5)
+    H, W = 360, 480
+    labels = np.zeros((H, W), np.int16)
+    ids = rng.permutation(np.arange(1, 30000))[:330]
+    k = 0
+    for by in range(15):
+        for bx in range(22):
+            labels[4 + by * 23: 4 + by * 23 + 17 + (k % 5), 3 + bx * 21: 3 + bx * 21 + 16 + (k % 3)] = ids[k]
+            k += 1
+    depth = (0.4 + 0.2 * rng.random((H, W))).astype(np.float32)
+    depth[::7, ::5] = 0.5                                        # repeated values: duplicates around the median
+    ols = L.OptimalLeafSelector("cuda:0")
+    ols.set_camera_params(np.array([[500.0, 0, 240, -20], [0, 500, 180, 0], [0, 0, 1, 0]]))
+    stats, (mn, mx), _ = ols.leaf_statistics(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda())
+    uniq = np.unique(labels)
+    uniq = uniq[uniq > 0]
+    assert len(uniq) == 330 and [s["id"] for s in stats] == uniq.tolist()
+    for s in stats[::7] + stats[-3:]:
+        lm = labels == s["id"]
+        ys, xs = np.where(lm)
+        assert s["area"] == int(lm.sum()) and s["sum_x"] == float(xs.sum()) and s["sum_y"] == float(ys.sum())
+        assert s["median_depth"] == np.median(depth[lm])
+        assert s["sum_depth"] == pytest.approx(float(depth[lm].astype(np.float64).sum()), rel=1e-12)
+    emn, emx = O.clutter_extrema(labels)
+    assert mn == tuple(int(v) for v in emn) and mx == tuple(int(v) for v in emx)
+    # the batched entry point: one frame with many labels beside ordinary ones
+    lab2, dep2, _ = O.synthetic_scene(H, W, 3)
+    out = ols.leaf_statistics_batch(torch.from_numpy(np.stack([lab2, labels, lab2])).cuda(),
+                                    torch.from_numpy(np.stack([dep2, depth, dep2])).cuda())
+    assert [s["id"] for s in out[1][0]] == uniq.tolist()
+    assert len(out[0][0]) == len(np.unique(lab2)) - 1
+    for a, b in zip(out[0][0], out[2][0]):   # (float sums are accumulated with atomics: equal to the last bit or two, not bitwise)
+        assert (a["id"], a["area"], a["sum_x"], a["sum_y"], a["median_depth"]) == (b["id"], b["area"], b["sum_x"], b["sum_y"], b["median_depth"])
+    for a, b in zip(out[1][0], stats):
+        assert a["area"] == b["area"] and a["median_depth"] == b["median_depth"]
+    # more than 1024 labels: that frame alone is refused (None), logged, never raised
+    many = np.zeros((H, W), np.int16)
+    many.reshape(-1)[:1100 * 3:3] = np.arange(1, 1101)
+    out = ols.leaf_statistics_batch(torch.from_numpy(np.stack([lab2, many])).cuda(), torch.from_numpy(np.stack([dep2, depth])).cuda())
+    assert out[0] is not None and out[1] is None
+    assert ols.select_optimal_leaf(torch.from_numpy(many).cuda(), torch.from_numpy(depth).cuda()) is None
+
+
+def test_clutter_argmax_branch_and_bound_adversarial(L):
+    """The arg-max of the exact distance field comes from a branch-and-bound pass on the leaf bit mask (lg_leaf.hip::k_edt_bb):
+    ties (first occurrence in row-major order), single pixels, lines, frames without / full of leaves, widths that are not a
+    multiple of 64 -- always the oracle's np.argmax of the exact field."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(9)
+    ols = L.OptimalLeafSelector("cuda:0")
+    ols.set_camera_params(np.array([[500.0, 0, 240, -20], [0, 500, 180, 0], [0, 0, 1, 0]]))
+    cases = []
+    for (H, W) in ((64, 64), (97, 133), (300, 517), (720, 1280)):
+        z = np.zeros((H, W), np.int16)
+        a = z.copy(); a[0, 0] = 1; cases.append(a)                              # far corner wins
+        a = z.copy(); a[H // 2, W // 2] = 2; cases.append(a)                    # four corners tie -> (0, 0)... or the nearest tie
+        a = z.copy(); a[H // 2, :] = 1; cases.append(a)                         # line: whole top / bottom rows tie
+        a = z.copy(); a[:, W // 3] = 3; cases.append(a)
+        a = z.copy(); a[0, 0] = a[H - 1, W - 1] = a[0, W - 1] = a[H - 1, 0] = 1; cases.append(a)   # centre region
+        a = np.ones((H, W), np.int16); a[H // 3, W // 5] = 0; cases.append(a)   # one background pixel
+        a = z.copy(); a[rng.random((H, W)) > 0.999] = 4; cases.append(a)        # sparse specks
+        a = z.copy(); a[::16, ::16] = 5; cases.append(a)                        # lattice: many equal maxima
+        a = (rng.random((H, W)) > 0.5).astype(np.int16); cases.append(a)        # dense noise: maxima of a few pixels
+        cases.append(np.ones((H, W), np.int16))                                 # no background pixel
+    for i, lab in enumerate(cases):
+        d = np.full(lab.shape, 0.5, np.float32)
+        _, (mn, mx), _ = ols.leaf_statistics(torch.from_numpy(lab).cuda(), torch.from_numpy(d).cuda())
+        leaf = lab >= 1
+        e = ndimage.distance_transform_edt(~leaf)
+        emx = np.unravel_index(e.argmax(), e.shape)
+        assert mx == tuple(int(v) for v in emx), f"case {i} {lab.shape}: {mx} vs {emx} (d2 {e[mx] ** 2} vs {e[emx] ** 2})"
+        emn = np.unravel_index(e.argmin(), e.shape)
+        assert mn == tuple(int(v) for v in emn), f"case {i}"
+    empty = np.zeros((100, 130), np.int16)
+    _, (mn, mx), _ = ols.leaf_statistics(torch.from_numpy(empty).cuda(), torch.from_numpy(np.zeros((100, 130), np.float32)).cuda())
+    assert mn == (0, 0) and mx == (0, 0)
+
+
 def test_leaf_selection_edge_cases(L):
     ols = L.OptimalLeafSelector("cuda:0")
     P = np.array([[300.0, 0, 100, -20], [0, 300, 80, 0], [0, 0, 1, 0]])
