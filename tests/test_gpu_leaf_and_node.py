@@ -314,3 +314,35 @@ def test_leaf_selection_batch_equals_per_frame(L):
     for chunks in (1, 2, 3, len(frames)):
         assert hz.process_batch_device(lab_d, dep_d, chunks=chunks) == csv_s, chunks
         assert hz.last_leaf_ids == ids
+
+
+def test_bench_two_ranks_one_device(tmp_path):
+    """The multi-GPU launch of bench.py rehearsed on this one-GPU box: the driver's command line
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 ...`) with both ranks on device 0 over
+    gloo (LG_BENCH_ONE_DEVICE=1; the real run puts one rank per GPU over RCCL).  Frames are sharded, nothing is exchanged on the
+    data path: rank 0 prints ONE JSON line whose value is the frames of BOTH ranks over the slowest rank's time."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", LG_BENCH_ONE_DEVICE="1")
+    steps, batch = 3, 8
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", str(steps),
+                          "--warmup", "1", "--batch", str(batch), "--height", "270", "--width", "360"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == steps and res["scaling"] == "weak" and res["unit"] == "frames/s"
+    assert res["config"]["frames_per_step_per_gpu"] == batch
+    # whole-job value: 2 ranks x batch x steps frames over the (max over ranks) time
+    assert res["value"] == pytest.approx(2 * batch * steps / (res["ms_per_step"] * steps * 1e-3), rel=2e-3)
+    assert "cpu_baseline" not in res and "roofline" in res      # the CPU leg is rank 0 at N = 1 only

@@ -74,6 +74,8 @@ def test_train_step_matches_reference_fixture(att, filt, n):
     assert [k for k, _ in parameter_layout(filt, att)[0]] == names     # model.named_parameters() order of the reference
     tr.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     loss, logits, gnorm = tr.train_step(x, y, masks=ones_masks(filt, n), return_logits=True)
+    own_g = [{k: v.numpy().copy() for k, v in tr.gradients().items()}]   # this path's own gradients, step by step
+    own_norm = [gnorm]
     assert loss == pytest.approx(float(tv[f"{tag}_loss0"]), rel=2e-5)
     np.testing.assert_allclose(logits.cpu().numpy(), tv[f"{tag}_logits0"], rtol=1e-4, atol=2e-5)
     assert gnorm == pytest.approx(float(tv[f"{tag}_gnorm0"]), rel=2e-4)
@@ -90,6 +92,8 @@ def test_train_step_matches_reference_fixture(att, filt, n):
     assert_close_robust(gs[tight], tv[f"{tag}_gsample0"][tight], 1e-3, 2e-5, 0.01, 2e-4, what="classifier gradient samples")
     # second step: Adam state carried on the device
     loss1, logits1, gnorm1 = tr.train_step(x, y, masks=ones_masks(filt, n), return_logits=True)
+    own_g.append({k: v.numpy().copy() for k, v in tr.gradients().items()})
+    own_norm.append(gnorm1)
     assert loss1 == pytest.approx(float(tv[f"{tag}_loss1"]), rel=2e-3)
     assert gnorm1 == pytest.approx(float(tv[f"{tag}_gnorm1"]), rel=3e-2)
     np.testing.assert_allclose(logits1.cpu().numpy(), tv[f"{tag}_logits1"], rtol=1e-2, atol=5e-3)
@@ -107,10 +111,44 @@ def test_train_step_matches_reference_fixture(att, filt, n):
     assert np.linalg.norm(ms - tv[f"{tag}_msample"]) <= 0.05 * np.linalg.norm(tv[f"{tag}_msample"])
     assert np.linalg.norm(vs - tv[f"{tag}_vsample"]) <= 0.10 * np.linalg.norm(tv[f"{tag}_vsample"])
     noisy = np.array([noisy_bias(k) for k in names])
-    # most parameters agree to 2e-5; where the gradient is rounding noise Adam steps by +-lr per step in either direction
-    assert_close_robust(ps[~noisy], tv[f"{tag}_psample"][~noisy], 1e-4, 2e-5, 0.08, 2e-3, what="params")
-    np.testing.assert_allclose(ps[~noisy], tv[f"{tag}_psample"][~noisy], atol=2 * 2 * 0.0005 + 1e-6)
-    np.testing.assert_allclose(ps[noisy], tv[f"{tag}_psample"][noisy], atol=2 * 2 * 0.0005 + 1e-6)
+    # Parameters after two optimisation steps.
+    # (1) The optimiser itself, free of any ReLU / max-pool decision: clip_grad_norm_(1.0) + torch.optim.Adam (L2 weight decay,
+    #     bias corrections; scripts/train_model.py:247-265) replayed on the host in float32 from THIS path's own two gradients
+    #     must give this path's parameters to rounding, every element of every tensor.
+    hp = tr.hp
+    lr, b1, b2, eps_, wd, mx = (np.float32(v) for v in (hp.lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.max_grad_norm))
+    one = np.float32(1.0)
+    for k in names:
+        pk = np.asarray(params[k], np.float32).copy()
+        m = np.zeros_like(pk)
+        v = np.zeros_like(pk)
+        for t_, (gd, gn) in enumerate(zip(own_g, own_norm), start=1):
+            coef = min(mx / (np.float32(gn) + np.float32(1e-6)), one)
+            gi = gd[k].astype(np.float32) * coef + wd * pk
+            m = b1 * m + (one - b1) * gi
+            v = b2 * v + (one - b2) * gi * gi
+            bc1, bc2 = one - b1 ** np.float32(t_), one - b2 ** np.float32(t_)
+            pk = pk - (lr / bc1) * (m / (np.sqrt(v) / np.sqrt(bc2) + eps_))
+        # (fp32 rounding of g * coef + wd * p where the two terms nearly cancel is amplified by 1 / sqrt(v): up to ~1e-6, 0.2 % of lr)
+        np.testing.assert_allclose(sd[k].numpy(), pk, rtol=2e-6, atol=2.5e-6, err_msg=f"Adam replay {k}")
+    # (2) Against the reference fixture.  Adam's first update is lr * sign(g) and later ones depend on RATIOS of gradients, so a
+    #     parameter can only leave the fixture's value where this path's gradient element differs from the reference's: where the
+    #     sampled gradients of BOTH steps agree (every tensor within 1e-3 of its RMS: no ReLU / max-pool decision fell the other
+    #     way in this case) at most 1 % of the elements may miss 1e-4; where a decision did flip (the fixture's second step of the
+    #     'hybrid' case and both steps of the 'channel' case do: gradients of whole tensors move by up to 1.7 % of their RMS) the
+    #     parameters are only held to the optimiser's own bound of 2 * lr per step -- (1) above is the check that cannot be
+    #     fooled there.
+    ref_p = tv[f"{tag}_psample"]
+    agree = True
+    for step in range(2):
+        ref_g = tv[f"{tag}_gsample{step}"]
+        rms = np.sqrt((ref_g.astype(np.float64) ** 2).mean(axis=1, keepdims=True)) + 1e-30
+        own = np.stack([own_g[step][k].reshape(-1)[pick[i]] for i, k in enumerate(names)])
+        agree &= bool((np.abs(own - ref_g) / rms)[~noisy].max() <= 1e-3)
+    bad = np.abs(ps - ref_p) > 2e-5 + 1e-4 * np.abs(ref_p)
+    if agree:
+        assert bad[~noisy].mean() <= 0.01, float(bad[~noisy].mean())
+    np.testing.assert_allclose(ps, ref_p, atol=2 * 2 * 0.0005 + 1e-6)
 
 
 @pytest.mark.parametrize("att,filt,n,seed", [("spatial", (64, 128, 256), 16, 1), ("none", (64, 128, 256, 512), 8, 2),
