@@ -317,7 +317,7 @@ def main():
             # + WRITE_SIZE), recorded per pixel in profiles/ by tools/pmc_final.sh; scaled to this launch.
             traffic = None
             try:
-                with open(os.path.join(REPO, "profiles", "r01_pmc_counters.json")) as fpmc:
+                with open(os.path.join(REPO, "profiles", "r02_pmc_counters.json")) as fpmc:
                     traffic = round(json.load(fpmc)["lg_final_kernel_summary"]["traffic_bytes_per_px"] * px)
             except Exception:  # noqa: BLE001
                 traffic = None

@@ -683,7 +683,14 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
 // One pass producing sdf_score, approach, flatness, isolation, accessibility, stem, traditional and the
 // validity mask (grasp_point_selector.py:256-288) from depth + mask bits + distance_map (+ frame scalars).
 // Tile 64 x LG_TH (16), 256 threads, each thread 4 consecutive pixels x LG_TH/16 rows (16-byte stores per lane).
-__global__ __launch_bounds__(256) void lg_final_kernel(LgFinalArgs a) {
+// Occupancy: the stencil path is latency bound (three LDS phases behind one global round trip per tile) and scales with the
+// waves in flight -- every tile on the stencil path, 128 frames of 1080p: 3.23 / 2.80 / 2.63 / 2.37 ms at 4 / 5 / 6-7 / 8 waves
+// per SIMD (tools/final_dense.py).  66 VGPRs gave 7; the attribute holds the allocation at 64 = 8 waves, no spills.
+#ifndef LG_FINAL_WPE
+#define LG_FINAL_WPE 8
+#endif
+#define LG_FINAL_WPE_ATTR __attribute__((amdgpu_waves_per_eu(LG_FINAL_WPE, LG_FINAL_WPE)))
+__global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinalArgs a) {
     constexpr int DW = 72;             // dm tile: cols tx0-4 .. tx0+67
     constexpr int DH = LG_TH + 6;      // rows ty0-3 .. ty0+34
     constexpr int GW = LG_TW + 2;      // g tile: cols tx0-1 .. tx0+64
