@@ -458,7 +458,7 @@ def main():
                 out["node_sequence"] = {"value": round(nb * args.node_steps / dt_n, 1), "unit": "frames/s",
                                         "frames_per_step": nb, "steps": args.node_steps,
                                         "results": sum(c is not None for c in csvs),
-                                        "what": "batched leaf selection (lg_leaf_stats_batch + host Pareto) + grasp "
+                                        "what": "batched leaf selection (lg_leaf_select_batch: device statistics + native host Pareto pick) + grasp "
                                                 "selection incl. CNN, int16 labels + depth resident in HBM"}
             except Exception as e:  # noqa: BLE001
                 out["node_sequence"] = {"error": str(e)}

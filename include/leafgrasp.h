@@ -181,6 +181,13 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
                         float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
                         void* stream);
 
+/* OptimalLeafSelector.select_optimal_leaf (scripts/utils/leaf_scorer.py:25-203) for B frames, the whole of it: the per-leaf
+   passes of lg_leaf_stats_batch and then, on the host inside the library, tall-leaf split, scores, Pareto filter and weighted
+   pick.  ids [B] HOST: the chosen label (-1: the reference's None; -2: a frame with more than 256 labels or 128 leaves -- take
+   it through lg_leaf_stats + the caller's own selection); n_tall [B], tall [B][tall_cap] HOST: get_tall_leaves() per frame. */
+int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
+                         double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, void* stream);
+
 /* GraspPointSelector.estimate_leaf_orientation (:718-752) for one frame: mask [H][W] u8 DEVICE.
    out (HOST, 5 floats): angle (rad, direction of the longer side of the min-area rectangle of the largest
    outer contour, in (0, pi]), major axis, minor axis, centre x, centre y.  Returns LG_OK and *found = 0

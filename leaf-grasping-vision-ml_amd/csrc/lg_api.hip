@@ -678,6 +678,21 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
     return LG_OK;
 }
 
+int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
+                         double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!labels || !depth || !ids || !n_tall || !tall || B < 1 || H < 1 || W < 1 || tall_cap < 1)
+        return fail(h, LG_ERR_INVALID, "lg_leaf_select_batch: bad argument");
+    hipStream_t s = (hipStream_t)stream_;
+    LG_HIP(h, hipSetDevice(h->device));
+    std::string err;
+    ProfScope ps(h, "leaf", s);
+    int rc = lg_leaf_select_batch_run(h->leaf, labels, depth, B, H, W, cx, cy, f, ids, n_tall, tall, tall_cap, s,
+                                      h->s_dt[0], &err);
+    if (rc) return fail(h, rc, err.c_str());
+    return LG_OK;
+}
+
 int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
     if (!h || !w) return LG_ERR_INVALID;
     LG_HIP(h, hipSetDevice(h->device));

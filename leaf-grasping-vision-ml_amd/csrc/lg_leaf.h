@@ -16,4 +16,9 @@ int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, 
 int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
                       float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
                       hipStream_t s, hipStream_t side, std::string* err);
+// statistics + the selection of leaf_scorer.py:53-181 for B frames in one call: ids [B] (-1: none; -2: a frame the caller
+// should take through the general path -- more than 256 labels or 128 leaves), n_tall [B], tall [B][tall_cap]
+int lg_leaf_select_batch_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
+                             double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, hipStream_t s, hipStream_t side,
+                             std::string* err);
 void lg_leaf_free(LgLeafWs*& w);

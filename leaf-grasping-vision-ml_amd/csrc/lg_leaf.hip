@@ -1040,6 +1040,125 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     return status ? LG_OK : worst;
 }
 
+// ---------------------------------------------------------------- the selection itself (host, O(#leaves) per frame)
+// OptimalLeafSelector.select_optimal_leaf after the per-leaf passes (scripts/utils/leaf_scorer.py:53-62, 74-181), the arithmetic
+// of leaf_scorer.py::_select_from_statistics restated in C++ with the same types and operation order: float32 medians and their
+// float32 mean with numpy's pairwise summation, float32 mean depth, float64 scores, non-dominated "max" filter keeping the first
+// of identical rows (paretoset 1.2.3), weighted 0.35 / 0.35 / 0.30 pick, first best wins.
+namespace {
+float np_sum_f32(const float* a, int n) {   // numpy's pairwise sum for n < 128 (one block): 8 partial sums, then the tail
+    if (n < 8) {
+        float r = 0.0f;     // numpy starts from -0.0; adding +0.0 vs -0.0 differs only for an all-(-0.0) input
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    float r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+}  // namespace
+
+// returns the chosen leaf id (-1: no result = the reference's None); tall: ids with median < mean of medians (capacity tall_cap)
+int lg_leaf_select_host(const lg_leaf_stat* st, int n, const int32_t ext[4], int H, int W, double cx, double cy, double f,
+                        int32_t* tall, int tall_cap, int* n_tall) {
+    *n_tall = 0;
+    // torch.unique(mask)[1:] skips the smallest value: the background 0 when present, else the first label (:32)
+    long long total = 0;
+    for (int i = 0; i < n; i++) total += st[i].area;
+    if (total == (long long)H * W && n > 0) { st++; n--; }
+    std::vector<float> med;
+    med.reserve(n);
+    for (int i = 0; i < n; i++)
+        if (st[i].area > 0) med.push_back(st[i].median_depth);
+    if (med.empty()) return -1;
+    const float depth_mean = med.size() >= 128 ? (float)0 : np_sum_f32(med.data(), (int)med.size()) / (float)med.size();
+    if (med.size() >= 128) return -2;   // (numpy switches to recursive halving there: the Python path handles such frames)
+    struct Cand { int id; double s[3]; bool tall; };
+    std::vector<Cand> cands;
+    std::vector<int> tall_ids;
+    for (int i = 0; i < n; i++)
+        if (st[i].median_depth < depth_mean) tall_ids.push_back(st[i].id);
+    for (int i = 0; i < n; i++) {
+        const double area = (double)st[i].area;
+        if (st[i].area < 10000) continue;                                            // :79-81
+        const double ctx = st[i].sum_x / area, cty = st[i].sum_y / area;              // :84-88
+        const double dmin = sqrt((ctx - ext[1]) * (ctx - ext[1]) + (cty - ext[0]) * (cty - ext[0]));
+        const double dmax = sqrt((ctx - ext[3]) * (ctx - ext[3]) + (cty - ext[2]) * (cty - ext[2]));
+        const double tot = dmin + dmax;
+        const double clutter = tot > 0 ? dmin / tot : 0.0;                            // :91-101
+        const float mean_depth = (float)(st[i].sum_depth / area);                     // np.mean of float32 depths (:105-106)
+        const double mean_distance = (double)mean_depth / f * (st[i].sum_ray / area);  // :109-115
+        const double dist_score = exp(-mean_distance / 0.3);                          // :117
+        double vis = 0.0;                                                             // :277-306
+        if (!st[i].touches_border) {
+            const double d = sqrt((ctx - W / 2.0) * (ctx - W / 2.0) + (cty - H / 2.0) * (cty - H / 2.0));
+            vis = 1.0 - d / sqrt((W / 2.0) * (W / 2.0) + (H / 2.0) * (H / 2.0));
+        }
+        Cand c;
+        c.id = st[i].id; c.s[0] = clutter; c.s[1] = dist_score; c.s[2] = vis;
+        c.tall = false;
+        for (int t_ : tall_ids) c.tall |= t_ == c.id;
+        cands.push_back(c);
+    }
+    if (cands.empty()) return -1;
+    bool any_tall = false;
+    for (auto& c : cands) any_tall |= c.tall;
+    std::vector<const Cand*> pool;
+    for (auto& c : cands)
+        if (c.tall == any_tall) pool.push_back(&c);
+    const double scale = any_tall ? 1.1 : 1.0;                                        // :150-160
+    const int m = (int)pool.size();
+    std::vector<char> keep(m, 1);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) {
+            if (i == j) continue;
+            bool ge = true, gt = false;
+            for (int k = 0; k < 3; k++) {
+                const double a = pool[j]->s[k] * scale, b = pool[i]->s[k] * scale;
+                if (a < b) { ge = false; break; }
+                if (a > b) gt = true;
+            }
+            if (ge && (gt || j < i)) { keep[i] = 0; break; }
+        }
+    bool any_keep = false;
+    for (int i = 0; i < m; i++) any_keep |= keep[i] != 0;
+    double best_s = -INFINITY;
+    int best = -1;
+    for (int i = 0; i < m; i++) {
+        if (any_keep && !keep[i]) continue;
+        const double ws = 0.35 * pool[i]->s[0] + 0.35 * pool[i]->s[1] + 0.3 * pool[i]->s[2];   // :170-181
+        if (ws > best_s) { best_s = ws; best = pool[i]->id; }
+    }
+    *n_tall = (int)tall_ids.size();
+    for (int i = 0; i < (int)tall_ids.size() && i < tall_cap; i++) tall[i] = tall_ids[i];
+    return best;
+}
+
+// statistics + selection for B frames, results only: ids [B] (-1 none, -2 "use the Python path"), n_tall [B], tall [B][tall_cap]
+int lg_leaf_select_batch_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
+                             double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, hipStream_t s, hipStream_t side,
+                             std::string* err) {
+    const int cap = 256;   // result rows per frame of this entry point (frames with more labels: -2, the caller's general path)
+    std::vector<lg_leaf_stat> stats((size_t)B * cap);
+    std::vector<int> nl(B), status(B);
+    std::vector<int32_t> ext((size_t)B * 4);
+    int rc = lg_leaf_run_batch(w, labels, depth, B, H, W, (float)cx, (float)cy, (float)f, stats.data(), cap, nl.data(), ext.data(), status.data(), s, side, err);
+    if (rc) return rc;
+    for (int b = 0; b < B; b++) {
+        n_tall[b] = 0;
+        if (status[b] == LG_ERR_INVALID) { ids[b] = -2; continue; }
+        if (status[b] != LG_OK) { ids[b] = -1; continue; }
+        ids[b] = lg_leaf_select_host(stats.data() + (size_t)b * cap, nl[b], ext.data() + 4 * (size_t)b, H, W, cx, cy, f,
+                                     tall + (size_t)b * tall_cap, tall_cap, &n_tall[b]);
+    }
+    return LG_OK;
+}
+
 int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
                 lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, hipStream_t side,
                 std::string* err) {

@@ -161,13 +161,38 @@ class OptimalLeafSelector:
         return out
 
     def select_optimal_leaves_batch(self, mask_tensors, depth_tensors):
-        """select_optimal_leaf for B frames with ONE device pass sequence -> list of leaf ids (or None)."""
+        """select_optimal_leaf for B frames in ONE library call (lg_leaf_select_batch: the device passes, then tall-leaf split,
+        scores, Pareto filter and weighted pick on the host inside the library -- the same arithmetic as
+        _select_from_statistics, without a Python loop over frames and leaves) -> list of leaf ids (or None)."""
         try:
-            per_frame = self.leaf_statistics_batch(mask_tensors, depth_tensors)
+            lab = torch.as_tensor(mask_tensors).to(self.device)
+            if lab.dtype != torch.int16:
+                lab = lab.to(torch.int16)
+            lab = lab.contiguous()
+            dep = torch.as_tensor(depth_tensors).to(self.device, torch.float32).contiguous()
+            B, H, W = lab.shape
+            tall_cap = 64
+            ids = (C.c_int32 * B)()
+            n_tall = (C.c_int32 * B)()
+            tall = (C.c_int32 * (B * tall_cap))()
+            with torch.cuda.device(self.device):
+                check(self._h, lib.lg_leaf_select_batch(self._h, lab.data_ptr(), dep.data_ptr(), B, H, W, float(self.camera_cx),
+                                                        float(self.camera_cy), float(self.f_norm), ids, n_tall, tall, tall_cap,
+                                                        _VP(torch.cuda.current_stream(self.device).cuda_stream)),
+                      "lg_leaf_select_batch")
         except Exception as e:  # noqa: BLE001
             logerr(f"Error in leaf selection: {str(e)}")
             return [None] * len(mask_tensors)
-        return self.select_from_statistics_batch(per_frame)
+        out, tall_b = [], []
+        for b in range(B):
+            if ids[b] == -2 or n_tall[b] > tall_cap:   # many labels / leaves: the general path for this frame
+                out.append(self.select_optimal_leaf(lab[b], dep[b]))
+                tall_b.append(self.get_tall_leaves() if out[-1] is not None else [])
+                continue
+            out.append(int(ids[b]) if ids[b] >= 0 else None)
+            tall_b.append([int(tall[b * tall_cap + k]) for k in range(n_tall[b])] if ids[b] >= 0 else [])
+        self._tall_leaves_batch = tall_b
+        return out
 
     def select_from_statistics_batch(self, per_frame):
         """The host half of select_optimal_leaves_batch: per-frame candidate scores, Pareto set and weighted pick from the
