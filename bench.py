@@ -242,7 +242,7 @@ def main():
     run_steps(2 * len(sels))
     torch.cuda.synchronize(dev)
     kern_all = {}
-    for name in ("prep", "bbox", "stem", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
+    for name in ("prep", "bbox", "orient", "stem", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
         tot_n, tot_ms = 0, 0.0
         for sel in sels:
             n, ms = C.c_int(0), C.c_double(0.0)

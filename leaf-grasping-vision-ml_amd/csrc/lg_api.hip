@@ -20,6 +20,7 @@
 #include "lg_cnn.h"
 #include "lg_leaf.h"
 #include "lg_internal.h"
+#include "lg_orient.h"
 #include "lg_pool.h"
 
 #define LG_VERSION_STR "leafgrasp-gfx950 0.1"
@@ -61,6 +62,8 @@ struct lg_ctx {
     float *h_info = nullptr, *h_logits = nullptr;
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
+    LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
+    hipEvent_t ev_orient = nullptr;
     int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -71,6 +74,7 @@ struct lg_ctx {
     int opt_no_skip = 0;         // LG_NO_SKIP=1: lg_final_kernel without the constant-tile fast path (dense-path roofline);
                                  //            =3: also without the wave-level off-leaf shortcut
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
+    bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
 namespace {
@@ -191,6 +195,11 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, hipHostMalloc((void**)&h->h_n, sizeof(int32_t) * nB));
     LG_HIP(h, hipHostMalloc((void**)&h->h_info, sizeof(float) * nB * nK * 2));
     LG_HIP(h, hipHostMalloc((void**)&h->h_logits, sizeof(float) * nB * nK));
+    if (!h->opt_host_orient && H <= 16384 && W <= 8192) {
+        std::string err;
+        const int rc = lg_orient_ensure(h->orient, nB, H, &err);
+        if (rc) return fail(h, rc, err.c_str());
+    }
     h->capB = nB; h->capH = H; h->capW = W; h->capK = nK;
     return LG_OK;
 }
@@ -268,7 +277,8 @@ int lg_create(int device, lg_handle* out) {
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess) {
         g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
@@ -298,6 +308,7 @@ int lg_create(int device, lg_handle* out) {
     h->opt_trace = getenv("LG_TRACE") != nullptr;
     if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e));
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
+    h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
@@ -312,6 +323,8 @@ int lg_destroy(lg_handle h) {
     free_ws(h);
     lg_cnn_free(&h->cnn);
     lg_leaf_free(h->leaf);
+    lg_orient_free(h->orient);
+    if (h->ev_orient) hipEventDestroy(h->ev_orient);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -393,6 +406,16 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
+    if (h->orient) {   // contour analysis on the device, beside the sweeps; the host reads theta / status back
+        {
+            ProfScope ps(h, "orient", h->copy_stream);
+            lg_launch_orient(h->orient, h->bits + off * words, h->win + off, h->fp_dev + off, off, n, pl.H, pl.W, pl.WW, h->copy_stream);
+        }
+        LG_HIP(h, hipMemcpyAsync(h->fp_host + off, h->fp_dev + off, sizeof(LgFrameParams) * n, hipMemcpyDeviceToHost, h->copy_stream));
+        LG_HIP(h, hipMemcpyAsync(h->orient->h_status + off, h->orient->status + off, sizeof(int) * n, hipMemcpyDeviceToHost,
+                                 h->copy_stream));
+        LG_HIP(h, hipEventRecord(h->ev_orient, h->copy_stream));
+    }
     if (h->bits_host_dev)   // rows of the bounding boxes only, posted writes by a small grid on the priority stream
         lg_launch_export_rows(h->bits + off * words, h->win + off, h->bits_host_dev + off * words, n, pl.H, pl.WW, h->copy_stream);
     else
@@ -433,34 +456,51 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     return LG_OK;
 }
 
-// host contour analysis of frames [off, off+n) (the bit rows must have landed: ev_copy synchronised)
-void host_orient(lg_ctx* h, const Plan& pl, int off, int n) {
-    const unsigned long long* hb = h->bits_host;
-    LgFrameParams* fph = h->fp_host;
-    const LgWin* wh = h->win_host;
+// host contour analysis of one frame (its bit rows must have landed: ev_copy synchronised)
+void host_orient_frame(lg_ctx* h, const Plan& pl, int b) {
     const int H = pl.H, W = pl.W, WW = pl.WW;
-    parallel_for(h, n, [=](int i) {
-        const int b = off + i;
-        double o[5];
-        // only the rows / words of the bounding box are on the host: analyse them as a band (the rest is all zero)
-        const LgWin& w = wh[b];
-        const int hy = w.by1 - w.by0 + 1;
-        int ok = hy > 0 ? lg_host_orientation_band(hb + ((size_t)b * H + w.by0) * WW, hy, W, WW, w.by0, w.bx0 >> 6, w.bx1 >> 6, o) : 0;
-        LgFrameParams f;
-        f.has_angle = ok;
-        f.theta = ok ? (float)o[0] : NAN;
-        f.sin_t = ok ? (float)sin(o[0]) : 0.f;
-        f.cos_t = ok ? (float)cos(o[0]) : 0.f;
-        fph[b] = f;
-    });
+    double o[5];
+    // only the rows / words of the bounding box are on the host: analyse them as a band (the rest is all zero)
+    const LgWin& w = h->win_host[b];
+    const int hy = w.by1 - w.by0 + 1;
+    int ok = hy > 0 ? lg_host_orientation_band(h->bits_host + ((size_t)b * H + w.by0) * WW, hy, W, WW, w.by0, w.bx0 >> 6, w.bx1 >> 6, o) : 0;
+    LgFrameParams f;
+    f.has_angle = ok;
+    f.theta = ok ? (float)o[0] : NAN;
+    f.sin_t = ok ? (float)sin(o[0]) : 0.f;
+    f.cos_t = ok ? (float)cos(o[0]) : 0.f;
+    h->fp_host[b] = f;
+}
+
+// Orientation of frames [off, off+n) into fp_host (and fp_dev).  Device path: wait for lg_orient_kernel's results (it runs
+// beside the sweeps on the side stream); frames it handed back (status 1: more runs than its scratch holds) are analysed on
+// the host threads.  LG_HOST_ORIENT: every frame on the host.  *upload = fp_host has entries the device does not have yet.
+int finish_orient(lg_ctx* h, const Plan& pl, int off, int n, bool* upload) {
+    *upload = true;
+    if (!h->orient) {
+        LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bit rows are on the host; the sweeps are running
+        parallel_for(h, n, [=, &pl](int i) { host_orient_frame(h, pl, off + i); });
+        return LG_OK;
+    }
+    LG_HIP(h, hipEventSynchronize(h->ev_orient));
+    std::vector<int> redo;
+    for (int i = 0; i < n; i++)
+        if (h->orient->h_status[off + i]) redo.push_back(off + i);
+    *upload = !redo.empty();
+    if (redo.empty()) return LG_OK;
+    LG_HIP(h, hipEventSynchronize(h->ev_copy));
+    const int* rp = redo.data();
+    parallel_for(h, (int)redo.size(), [=, &pl](int i) { host_orient_frame(h, pl, rp[i]); });
+    return LG_OK;
 }
 
 // frame scalars H2D + the fused score-plane kernel
-int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
+int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upload_fp) {
     const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
     const int H = pl.H, W = pl.W;
     const lg_params& P = pl.P;
-    LG_HIP(h, hipMemcpyAsync(h->fp_dev + off, h->fp_host + off, sizeof(LgFrameParams) * n, hipMemcpyHostToDevice, s));
+    if (h->orient) LG_HIP(h, hipStreamWaitEvent(s, h->ev_orient, 0));   // fp_dev was written on the side stream
+    if (upload_fp) LG_HIP(h, hipMemcpyAsync(h->fp_dev + off, h->fp_host + off, sizeof(LgFrameParams) * n, hipMemcpyHostToDevice, s));
     LgFinalArgs a;
     memset(&a, 0, sizeof(a));
     a.depth = pl.depth + off * px; a.bits = h->bits + off * words; a.stem_bits = h->stem + off * words;
@@ -539,12 +579,13 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
     if (rc) return rc;
     rc = enq_dt(h, pl, 0, B, s);
     if (rc) return rc;
-    // ---- orientation hand-off: host contour analysis overlaps the distance-transform sweeps
-    LG_HIP(h, hipEventSynchronize(h->ev_copy));
-    host_orient(h, pl, 0, B);
+    // ---- orientation: lg_orient_kernel beside the distance-transform sweeps (host threads for frames it hands back)
+    bool upload_fp = true;
+    rc = finish_orient(h, pl, 0, B, &upload_fp);
+    if (rc) return rc;
     if (theta_host)
         for (int b = 0; b < B; b++) theta_host[b] = h->fp_host[b].theta;
-    rc = enq_final(h, pl, 0, B, s);
+    rc = enq_final(h, pl, 0, B, s, upload_fp);
     if (rc) return rc;
     LG_HIP(h, hipGetLastError());
     return LG_OK;
@@ -640,9 +681,21 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
     if (rc) return rc;
     const int WW = (W + 63) / 64;
     lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
+    double o[5];
+    if (h->orient) {   // the device analysis; a mask with more runs than its scratch holds falls through to the host code
+        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, s);
+        lg_launch_orient(h->orient, h->bits, h->win, h->fp_dev, 0, 1, H, W, WW, s);
+        LG_HIP(h, hipMemcpyAsync(h->orient->h_out, h->orient->out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
+        LG_HIP(h, hipMemcpyAsync(h->orient->h_status, h->orient->status, sizeof(int), hipMemcpyDeviceToHost, s));
+        LG_HIP(h, hipStreamSynchronize(s));
+        if (!h->orient->h_status[0]) {
+            *found = !std::isnan(h->orient->h_out[0]);
+            for (int i = 0; i < 5; i++) out[i] = *found ? (float)h->orient->h_out[i] : NAN;
+            return LG_OK;
+        }
+    }
     LG_HIP(h, hipMemcpyAsync(h->bits_host, h->bits, sizeof(unsigned long long) * (size_t)H * WW, hipMemcpyDeviceToHost, s));
     LG_HIP(h, hipStreamSynchronize(s));
-    double o[5];
     *found = lg_host_orientation(h->bits_host, H, W, WW, o);
     for (int i = 0; i < 5; i++) out[i] = *found ? (float)o[i] : NAN;
     return LG_OK;
@@ -813,14 +866,15 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     }
     if (trace && !piped) hipEventRecord(tev[1], s);   // after the sweeps
     const double t_enq1 = now();
-    LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bit rows are on the host; the sweeps are running
     const double t_copy = now();
-    host_orient(h, pl, 0, B);
+    bool upload_fp = true;
+    rc = finish_orient(h, pl, 0, B, &upload_fp);   // theta per frame: device results (or host analysis) while the sweeps run
+    if (rc) return rc;
     const double t_orient = now();
     for (int k = 0; k < nsub; k++) {
         const int off = k * SB, n = std::min(SB, B - off);
         if (piped) LG_HIP(h, hipStreamWaitEvent(sM, EV(k, 2), 0));
-        rc = enq_final(h, pl, off, n, sM);
+        rc = enq_final(h, pl, off, n, sM, upload_fp);
         if (rc) return rc;
         if (trace && !piped) hipEventRecord(tev[2], s);   // after the fused planes
         if (piped) {
@@ -853,6 +907,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     LG_HIP(h, hipMemcpyAsync(h->h_info, h->cand_info, sizeof(float) * B * K * 2, hipMemcpyDeviceToHost, s));
     const double t_enq2 = now();
     LG_HIP(h, hipStreamSynchronize(s));
+    LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bounding-box bit rows for the pre-grasp clearance test below
     const double t_sync = now();
     LG_HIP(h, hipGetLastError());
     std::vector<float> theta(B);

@@ -1,5 +1,7 @@
 """GPU parity of the leaf-selection stage (OptimalLeafSelector), the ROS-free node harness and the
 HybridGraspSelector facade against the CPU oracle."""
+import math
+
 import numpy as np
 import pytest
 
@@ -216,6 +218,121 @@ def test_estimate_leaf_orientation(L):
         assert got[1] == pytest.approx(exp[1], rel=1e-5) and got[2] == pytest.approx(exp[2], rel=1e-5)
         assert got[3] == pytest.approx(exp[3], rel=1e-5)
     assert sel.estimate_leaf_orientation(np.zeros((64, 64), np.uint8)) == (None, None, None, None)
+
+
+def _orientation_cases():
+    """Masks for the contour analysis: the shapes of tests/test_host_contour.py (noise, sparse specks, an ellipse with a hole
+    and a fragment, full frames, ragged bands) plus leaf-like scenes with several components, thin bridges and spirals."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for case in range(120):
+        H, W = int(rng.integers(3, 90)), int(rng.integers(3, 200))
+        kind = case % 6
+        yy, xx = np.mgrid[0:H, 0:W]
+        if kind == 0:
+            m = rng.random((H, W)) > 0.6
+        elif kind == 1:
+            m = rng.random((H, W)) > 0.97
+        elif kind == 2:
+            m = ((xx - W * 0.5) / (W * 0.4)) ** 2 + ((yy - H * 0.5) / (H * 0.35)) ** 2 <= 1
+            m &= ~(((xx - W * 0.5) / (W * 0.15)) ** 2 + ((yy - H * 0.5) / (H * 0.12)) ** 2 <= 1)   # a hole
+            m[0, :3] = True
+        elif kind == 3:
+            m = np.ones((H, W), bool)
+        elif kind == 4:
+            m = np.zeros((H, W), bool)
+            h4 = min(max(1, H // 4), H - H // 3)
+            m[H // 3: H // 3 + h4, :] = rng.random((h4, W)) > 0.3
+        else:   # a rotated bar and a diagonal one-pixel line joined to it (the border passes the line's pixels twice)
+            a = rng.uniform(0, np.pi)
+            u = (xx - W / 2) * np.cos(a) + (yy - H / 2) * np.sin(a)
+            v = -(xx - W / 2) * np.sin(a) + (yy - H / 2) * np.cos(a)
+            m = (np.abs(u) < W * 0.3) & (np.abs(v) < max(1.5, H * 0.08))
+            k = np.arange(min(H, W))
+            m[k, k] = True
+        cases.append(m.astype(np.uint8))
+    for seed in range(6):   # leaf-sized: one leaf of a 1080p scene, all leaves together, two disjoint leaves
+        labels, _, _ = O.synthetic_scene(1080, 1920, 60 + seed)
+        ids = [i for i in np.unique(labels) if i]
+        cases.append((labels == ids[seed % len(ids)]).astype(np.uint8))
+        cases.append((labels > 0).astype(np.uint8))
+        cases.append(np.isin(labels, ids[:2]).astype(np.uint8))
+    yy, xx = np.mgrid[0:600, 0:800]
+    r, t = np.hypot(xx - 400, yy - 300), np.arctan2(yy - 300, xx - 400)
+    cases.append((np.abs(((r / 12 - t / (2 * np.pi)) % 1.0) - 0.5) < 0.2).astype(np.uint8))          # spiral: one long border
+    cases.append(((xx // 3 + yy // 3) % 2 == 0).astype(np.uint8))                                     # 3x3 checkerboard: corner-connected
+    cases.append(((xx % 4 == 0) & (yy % 4 == 0)).astype(np.uint8))                                    # 30000 single pixels
+    one = np.zeros((50, 70), np.uint8); one[20, 30] = 1
+    cases.append(one)
+    line = np.zeros((50, 70), np.uint8); line[25, 5:60] = 1
+    cases.append(line)
+    col = np.zeros((50, 70), np.uint8); col[5:45, 69] = 1
+    cases.append(col)
+    diag = np.zeros((64, 64), np.uint8); diag[np.arange(64), np.arange(64)] = 1
+    cases.append(diag)
+    return cases
+
+
+@pytest.mark.parametrize("cap", [None, "64"])
+def test_orientation_device_equals_host(L, cap, monkeypatch):
+    """estimate_leaf_orientation (grasp_point_selector.py:718-752) on the device (lg_orient_kernel: runs, union-find, border
+    following, hull chains, min-area rectangle) against the host analysis it replaces (lg_contour.cpp, LG_HOST_ORIENT=1; that
+    one is held against the oracle bit for bit in tests/test_host_contour.py): the same five numbers as float32, for every
+    case.  cap = 64 runs of scratch: most cases exceed it and must come back through the host hand-off."""
+    monkeypatch.setenv("LG_HOST_ORIENT", "1")
+    host = L.GraspPointSelector("cuda:0", load_model=False)
+    monkeypatch.delenv("LG_HOST_ORIENT")
+    if cap:
+        monkeypatch.setenv("LG_ORIENT_CAP", cap)
+    dev = L.GraspPointSelector("cuda:0", load_model=False)
+    n_found = 0
+    for k, m in enumerate(_orientation_cases()):
+        want = host.estimate_leaf_orientation(m)
+        got = dev.estimate_leaf_orientation(m)
+        assert (want[0] is None) == (got[0] is None), k
+        if want[0] is None:
+            continue
+        n_found += 1
+        # float32 of the same float64 results; atan2 / fmod of the device library may differ from glibc in the last bit
+        # of the double, i.e. never after rounding to float32 except on a rounding boundary
+        assert got[0] == pytest.approx(want[0], abs=2e-7), (k, got, want)
+        assert got[1:] == want[1:], (k, got, want)
+    assert n_found > 130
+
+
+def test_orientation_in_the_batched_path(L, monkeypatch):
+    """lg_select_grasp with the orientation kernel beside the sweeps: theta and the score planes (the approach plane takes
+    sin / cos of theta) equal the host-orientation path for a batch that mixes ordinary leaves, an empty mask, several
+    components and a frame that overflows a small scratch (LG_ORIENT_CAP) and is handed back to the host threads."""
+    H, W = 540, 720
+    frames = [O.synthetic_scene(H, W, 70 + i) for i in range(6)]
+    masks = np.stack([(f[0] == 1) for f in frames]).astype(np.uint8)
+    masks[1][:] = 0
+    masks[2] = (frames[2][0] > 0)
+    rng = np.random.default_rng(3)
+    masks[3] |= (rng.random((H, W)) > 0.98).astype(np.uint8)      # thousands of runs
+    depths = np.stack([f[1] for f in frames])
+    P = frames[0][2]
+    monkeypatch.setenv("LG_HOST_ORIENT", "1")
+    host = L.GraspPointSelector("cuda:0", load_model=False)
+    monkeypatch.delenv("LG_HOST_ORIENT")
+    monkeypatch.setenv("LG_ORIENT_CAP", "2048")
+    dev = L.GraspPointSelector("cuda:0", load_model=False)
+    out = []
+    for sel in (host, dev):
+        sel.set_camera_params(P)
+        res, maps, valid = sel.select_grasp_points_batch(torch.from_numpy(masks).cuda(), torch.from_numpy(depths).cuda(),
+                                                         return_maps=True)
+        out.append((res, {k: v.cpu().numpy() for k, v in maps.items()}, valid.cpu().numpy(),
+                    [r.theta for r in sel.last_results]))
+    (res_h, maps_h, valid_h, th_h), (res_d, maps_d, valid_d, th_d) = out
+    assert math.isnan(th_h[1]) and math.isnan(th_d[1])
+    for b in (0, 2, 3, 4, 5):
+        assert th_d[b] == pytest.approx(th_h[b], abs=2e-7), b
+    assert res_d == res_h
+    np.testing.assert_array_equal(valid_d, valid_h)
+    for k in maps_h:
+        np.testing.assert_allclose(maps_d[k], maps_h[k], rtol=0, atol=1e-6, err_msg=k)
 
 
 def test_node_harness_end_to_end(L):
