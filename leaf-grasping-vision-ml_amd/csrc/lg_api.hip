@@ -526,8 +526,11 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     }
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
+    a.inv_2s2 = 1.0f / (2.0f * P.optimal_distance * P.optimal_distance);   // (correctly rounded, like the device's __frcp_rn)
+    a.iso_ramp_step = (H > 1) ? (P.iso_ramp_bottom - P.iso_ramp_top) / (float)(H - 1) : 0.0f;
     gaussian1d(a.k1);
     a.no_skip = h->opt_no_skip;
+    a.persist = 1;
     a.nt_stores = h->opt_nt_stores ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
         ProfScope ps(h, "final", s, true);

@@ -70,9 +70,11 @@ struct LgFinalArgs {
     float iso_w_close, iso_w_wide, iso_ramp_top, iso_ramp_bottom, iso_inv_max;
     float min_edge_distance, stem_valid_thresh;
     float inv_maxd;
+    float inv_2s2, iso_ramp_step;   // 1 / (2 optimal_distance^2) (float32 reciprocal), (ramp_bottom - ramp_top) / (H - 1)
     float k1[5];  // separable 1-D Gaussian (size 5, sigma 5/6)
     int no_skip;    // 1: disable the off-mask fast path (LG_NO_SKIP=1, A/B measurements)
     int nt_stores;  // 0: plain stores (default); 1: non-temporal plane stores (LG_NT_STORES=1; measured slower)
+    int persist;    // 1: resident workgroups walk the tiles (lg_launch_final); 0: one workgroup per tile
 };
 
 // kernel launchers (lg_kernels.hip)

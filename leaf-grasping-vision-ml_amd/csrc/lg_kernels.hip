@@ -683,14 +683,31 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
 // One pass producing sdf_score, approach, flatness, isolation, accessibility, stem, traditional and the
 // validity mask (grasp_point_selector.py:256-288) from depth + mask bits + distance_map (+ frame scalars).
 // Tile 64 x LG_TH (16), 256 threads, each thread 4 consecutive pixels x LG_TH/16 rows (16-byte stores per lane).
-// Occupancy: the stencil path is latency bound (three LDS phases behind one global round trip per tile) and scales with the
-// waves in flight -- every tile on the stencil path, 128 frames of 1080p: 3.23 / 2.80 / 2.63 / 2.37 ms at 4 / 5 / 6-7 / 8 waves
-// per SIMD (tools/final_dense.py).  66 VGPRs gave 7; the attribute holds the allocation at 64 = 8 waves, no spills.
+//
+// Launch shape: one workgroup per tile, or (LG_FINAL_PERSIST, lg_launch_final) resident workgroups that walk the tiles; the
+// same code serves both -- blockIdx % 8 is the XCD, every XCD owns a contiguous range of tiles and its workgroups take them
+// with the XCD's workgroup count as stride, so neighbouring workgroups work on neighbouring tiles at the same time (shared
+// halos hit in the XCD's L2).
+// What the tile loop needs from the code: nothing loop-invariant may stay in registers across tiles at 64 VGPRs (8 waves per
+// SIMD; 66 gave 7) -- the arguments are read through the kernarg pointer, laundered once per tile (their ~60 scalar loads then
+// belong to the iteration instead of being hoisted: without this 156 SGPRs + 39 VGPRs spilled), the thread index likewise
+// (indices and LDS addresses are recomputed per tile), the tile walk is 32-bit scalar arithmetic, frame scalars come
+// through the scalar cache, and the barriers order LDS only (s_waitcnt lgkmcnt(0)): __syncthreads() would also wait for the
+// previous tile's plane stores to be acknowledged.
+// What bounds it (tools/ubench/stream_mix.hip, tools/final_ablate.sh, one box): a kernel with ONLY this path's loads and
+// stores in the same 64 x 16 tile shape reaches 0.72 of the 8 TB/s peak (1.70 ms per 128 frames; a plain 2-read + 1-write copy
+// 0.65, the nine stores alone 0.84, 256 x 4 tiles 0.82); this kernel with its arithmetic removed 1.98 ms, complete 2.21 ms.
+// Occupancy: the stencil path scales with the waves in flight -- every tile on the stencil path, 128 frames of 1080p, one
+// workgroup per tile: 3.23 / 2.80 / 2.63 / 2.37 ms at 4 / 5 / 6-7 / 8 waves per SIMD (tools/final_dense.py).
 #ifndef LG_FINAL_WPE
 #define LG_FINAL_WPE 8
 #endif
 #define LG_FINAL_WPE_ATTR __attribute__((amdgpu_waves_per_eu(LG_FINAL_WPE, LG_FINAL_WPE)))
-__global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinalArgs a) {
+__device__ __forceinline__ float lg_uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// VEC: W % 4 == 0 (16-byte loads / stores everywhere); ALL: every plane and the validity plane are wanted (the grasp-selection
+// call with the CNN): the instantiation for the usual case carries no per-plane null checks and no scalar store paths.
+template <bool VEC, bool ALL>
+__global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinalArgs a_) {
     constexpr int DW = 72;             // dm tile: cols tx0-4 .. tx0+67
     constexpr int DH = LG_TH + 6;      // rows ty0-3 .. ty0+34
     constexpr int GW = LG_TW + 2;      // g tile: cols tx0-1 .. tx0+64
@@ -700,95 +717,134 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     float* const s_g = s_dm;  // the smoothed tile reuses the depth tile's LDS (dead after the horizontal pass)
     static_assert(GH * (GW + 2) <= DH * DW, "g tile must fit in the depth tile");
     __shared__ unsigned long long s_key[4];
+    __shared__ int s_any[2];
+    typedef float lg_f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) LgFinalArgs* lg_args_ptr;
+    lg_args_ptr ap = (lg_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_;
 
-    // XCD-aware remap: each XCD (blockIdx % 8 group) walks a contiguous range of tiles
-    const int ntile = a.tiles_x * a.tiles_y;
-    const long long total = (long long)ntile * a.B;
-    long long id = blockIdx.x;
-    {
-        long long q = total / 8, r = total % 8;
-        long long xcd = id % 8, j = id / 8;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int frame = (int)(id / ntile);
-    const int tile = (int)(id % ntile);
-    const int bx = tile % a.tiles_x, by = tile / a.tiles_x;
+    // ---- the tile walk, in scalar registers (total < 2^31: lg_launch_final)
+    const int ntile = ap->tiles_x * ap->tiles_y;
+    const int total = ntile * ap->B;
+    const int xcd = (int)(blockIdx.x & 7u), tq = total >> 3, tr = total & 7;
+    const int xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int xcd_count = tq + (xcd < tr ? 1 : 0);
+    const int stride = (int)((gridDim.x + 7u) >> 3);
+    int it = (int)(blockIdx.x >> 3);
+    if (it >= xcd_count) return;
+    int frame = __builtin_amdgcn_readfirstlane((xcd_first + it) / ntile);
+    int tile = xcd_first + it - frame * ntile;
+    const int step_f = __builtin_amdgcn_readfirstlane(stride / ntile), step_t = stride - step_f * ntile;
+    for (int par = 0; it < xcd_count;
+         par ^= 1, it += stride, frame += step_f, tile += step_t, frame += (tile >= ntile ? 1 : 0), tile -= (tile >= ntile ? ntile : 0)) {
+    asm volatile("" : "+s"(ap));
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int tiles_x = ap->tiles_x;
+    // tile < 8192, tiles_x <= 128: the float quotient of (tile + 0.5) is at least 0.5 / 128 away from an integer, its error < 0.001
+    const int by = __builtin_amdgcn_readfirstlane((int)(((float)tile + 0.5f) * __frcp_rn((float)tiles_x)));
+    const int bx = tile - by * tiles_x;
     const int tx0 = bx * LG_TW, ty0 = by * LG_TH;
-    const int H = a.H, W = a.W, WW = a.WW;
-    const int t = threadIdx.x;
+    const int H = ap->H, W = ap->W, WW = ap->WW;
     const size_t fo = (size_t)frame * H * W;
-    const float* depth = a.depth + fo;
-    const unsigned long long* bits = a.bits + (size_t)frame * H * WW;
+    const char* depth = (const char*)(ap->depth + fo);
+    const char* bits = (const char*)(ap->bits + (size_t)frame * H * WW);
+    const char* stemb = (const char*)(ap->stem_bits + (size_t)frame * H * WW);
+    auto bits_at = [&](const char* base, int y, int w) {   // uniform base + 32-bit lane offset (saddr addressing)
+        return *reinterpret_cast<const unsigned long long*>(base + (unsigned)(y * WW + w) * 8u);
+    };
 
     const int txi = t & 15, tyi = t >> 4;
-    const unsigned long long* stemb = a.stem_bits + (size_t)frame * H * WW;
-    const bool vec = ((W & 3) == 0);  // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
+    constexpr bool vec = VEC;         // x0 % 4 == 0 always; x0 + 3 < W when W % 4 == 0
     constexpr int RPT = LG_TH / 16;   // rows per thread (16 thread rows per tile)
     static_assert(LG_TH % 16 == 0 && RPT >= 1, "tile height must be a multiple of 16");
     // distance_map is only computed inside the frame's sweep window (LgWin, tile aligned); outside it is exactly 0 and
     // this kernel writes the plane instead of reading it
-    const LgWin win = a.win[frame];
-    const bool in_win = tx0 >= win.wx0 && tx0 < min(W, win.wx0 + win.nw * a.win_wc) && ty0 >= win.wy0 && ty0 < win.wy1;
+    // (win / fp / maxfix were written by earlier kernels and are only read here: constant-address-space loads, i.e. the
+    //  scalar cache, instead of a vector load + readfirstlane per value)
+    bool in_win;
+    {
+        const __attribute__((address_space(4))) LgWin* wp = (const __attribute__((address_space(4))) LgWin*)(ap->win + frame);
+        const int wx0 = wp->wx0;
+        in_win = tx0 >= wx0 && tx0 < min(W, wx0 + wp->nw * ap->win_wc) && ty0 >= wp->wy0 && ty0 < wp->wy1;
+    }
+    // 4 floats of one plane at pixel offset `off` of this frame (uniform plane base + 32-bit byte offset)
+    auto st4 = [&](int mi, unsigned off, int x0, const float* v) {
+        float* dst = ap->maps[mi];
+        if (!ALL && !dst) return;
+        if ((ap->no_skip & 8) && mi != LG_MAP_TRADITIONAL) return;   // ablation: arithmetic without the plane stores
+        char* p = (char*)(dst + fo) + off * 4u;
+        if (vec) {
+            lg_f4 pk = {v[0], v[1], v[2], v[3]};
+            if (ap->nt_stores) __builtin_nontemporal_store(pk, reinterpret_cast<lg_f4*>(p));  // write-once stream (measured slower)
+            else *reinterpret_cast<lg_f4*>(p) = pk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x0 + j < W) reinterpret_cast<float*>(p)[j] = v[j];
+        }
+    };
+    auto st_valid = [&](unsigned off, int x0, uint32_t vbytes) {
+        if (!ALL && !ap->valid) return;
+        uint8_t* p = ap->valid + fo + off;
+        if (vec) {
+            __builtin_nontemporal_store(vbytes, reinterpret_cast<uint32_t*>(p));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x0 + j < W) p[j] = (uint8_t)((vbytes >> (8 * j)) & 1u);
+        }
+    };
+    float zero = 0.0f;
+    asm volatile("" : "+v"(zero));   // (a zero the compiler cannot keep in registers across tiles)
     // ---- tile-level fast path.  A leaf covers a few per cent of the frame: when no mask bit lies in this tile's extended
     //      region (tile + the 3-pixel reach of the 5x5 Gaussian and 3x3 Sobel), depth * mask is 0 all over it, the smoothed
     //      plane and both gradients are 0 and flatness = exp(-5 * 0) = 1 exactly; every other plane is "* mask" = 0,
     //      traditional = w_flat * 1, nothing is valid.  Such tiles never read depth and skip the stencil phases.
-    {
-        unsigned long long nz = 0;
-        if (t < DH * 3 && !a.no_skip) {
-            const int er = t / 3, wq = t % 3;                 // extended row, word (left neighbour, own, right neighbour)
-            const int y = lg_reflect(ty0 - 3 + er, H), wi = bx - 1 + wq;
-            if (wi >= 0 && wi < WW) {
-                nz = bits[(size_t)y * WW + wi];
-                if (wq == 0) nz >>= 56;                       // columns tx0-8 .. tx0-1 (halo 4 + reflection slack)
-                if (wq == 2) nz &= 0xffull;                   // columns tx0+64 .. tx0+71
+    //      Wave 0 looks at the DH x 3 (row, word) pairs and posts the verdict; s_any alternates between two slots so that a
+    //      wave that runs ahead into the next tile cannot overwrite a verdict the others have not read yet.
+    if (!ap->no_skip) {
+        if (t < 64) {
+            unsigned long long nz = 0;
+#pragma unroll
+            for (int e = t; e < DH * 3; e += 64) {
+                const int er = e / 3, wq = e % 3;                 // extended row, word (left neighbour, own, right neighbour)
+                const int y = lg_reflect(ty0 - 3 + er, H), wi = bx - 1 + wq;
+                if (wi >= 0 && wi < WW) {
+                    unsigned long long v = bits_at(bits, y, wi);
+                    if (wq == 0) v >>= 56;                        // columns tx0-8 .. tx0-1 (halo 4 + reflection slack)
+                    if (wq == 2) v &= 0xffull;                    // columns tx0+64 .. tx0+71
+                    nz |= v;
+                }
             }
+            const bool any = __ballot(nz != 0) != 0ull;
+            if (t == 0) s_any[par] = any ? 1 : 0;
         }
-        if (!a.no_skip && !__syncthreads_or(nz != 0)) {
-            const float flat1 = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(0.0f));
+        lg_lds_barrier();
+        if (!s_any[par]) {
+            const float flat1 = __expf(-ap->flat_scale * __builtin_amdgcn_sqrtf(zero));
+            const float tr1 = ap->w_flat * flat1;
             const float c_flat[4] = {flat1, flat1, flat1, flat1};
-            const float tr = a.w_flat * flat1;
-            const float c_trad[4] = {tr, tr, tr, tr};
-            const float c_zero[4] = {0.f, 0.f, 0.f, 0.f};
+            const float c_trad[4] = {tr1, tr1, tr1, tr1};
+            const float c_zero[4] = {zero, zero, zero, zero};
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) {
                 const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
                 if (y < H && x0 < W) {
-                    const size_t off = fo + (size_t)y * W + x0;
-                    auto st4c = [&](int mi, const float* v) {
-                        float* dst = a.maps[mi];
-                        if (!dst) return;
-                        if (vec) {
-                            typedef float lg_f4 __attribute__((ext_vector_type(4)));
-                            lg_f4 pk = {v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<lg_f4*>(dst + off) = pk;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (x0 + j < W) dst[off + j] = v[j];
-                        }
-                    };
-                    st4c(LG_MAP_SDF, c_zero); st4c(LG_MAP_APPROACH, c_zero); st4c(LG_MAP_FLATNESS, c_flat);
-                    st4c(LG_MAP_ISOLATION, c_zero); st4c(LG_MAP_ACCESS, c_zero); st4c(LG_MAP_STEM, c_zero);
-                    st4c(LG_MAP_TRADITIONAL, c_trad);
-                    if (!in_win) st4c(LG_MAP_DISTANCE, c_zero);
-                    if (a.valid) {
-                        if (vec) {
-                            __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(a.valid + off));
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (x0 + j < W) a.valid[off + j] = 0;
-                        }
-                    }
+                    const unsigned off = (unsigned)(y * W + x0);
+                    st4(LG_MAP_SDF, off, x0, c_zero); st4(LG_MAP_APPROACH, off, x0, c_zero); st4(LG_MAP_FLATNESS, off, x0, c_flat);
+                    st4(LG_MAP_ISOLATION, off, x0, c_zero); st4(LG_MAP_ACCESS, off, x0, c_zero); st4(LG_MAP_STEM, off, x0, c_zero);
+                    st4(LG_MAP_TRADITIONAL, off, x0, c_trad);
+                    if (!in_win) st4(LG_MAP_DISTANCE, off, x0, c_zero);
+                    st_valid(off, x0, 0u);
                 }
             }
             if (t == 0) {   // arg-max key of a tile without valid pixels: score 0, largest flat index (top-k tie rule)
                 const int ymax = min(ty0 + LG_TH, H) - 1, xmax = min(tx0 + LG_TW, W) - 1;
-                a.tilekeys[(size_t)frame * ntile + tile] =
+                ap->tilekeys[(size_t)frame * ntile + tile] =
                     ((unsigned long long)lg_orderable(0.0f) << 32) | (uint32_t)(ymax * W + xmax);
             }
-            return;
+            continue;
         }
     }
 
@@ -803,29 +859,29 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
         for (int j = 0; j < 4; j++) din_pre[rr][j] = 0.0f;
         if (y < H && x0 < W) {
             const unsigned sh = (unsigned)(x0 & 63);
-            mnib_pre[rr] = (unsigned)(bits[(size_t)y * WW + bx] >> sh) & 0xfu;
-            snib_pre[rr] = (unsigned)(stemb[(size_t)y * WW + bx] >> sh) & 0xfu;
-            const float* dsrc = a.maps[LG_MAP_DISTANCE] + fo + (size_t)y * W + x0;
+            mnib_pre[rr] = (unsigned)(bits_at(bits, y, bx) >> sh) & 0xfu;
+            snib_pre[rr] = (unsigned)(bits_at(stemb, y, bx) >> sh) & 0xfu;
+            const char* dsrc = (const char*)(ap->maps[LG_MAP_DISTANCE] + fo) + (unsigned)(y * W + x0) * 4u;
             if (!in_win) {
             } else if (vec) {
                 float4 v = *reinterpret_cast<const float4*>(dsrc);
                 din_pre[rr][0] = v.x; din_pre[rr][1] = v.y; din_pre[rr][2] = v.z; din_pre[rr][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) din_pre[rr][j] = (x0 + j < W) ? dsrc[j] : 0.0f;
+                for (int j = 0; j < 4; j++) din_pre[rr][j] = (x0 + j < W) ? reinterpret_cast<const float*>(dsrc)[j] : 0.0f;
             }
         }
     }
 
     // ---- stage dm = depth * mask over the extended tile (reflect padding of smooth_depth, image_processor.py:60)
-    const bool fast = ((W & 3) == 0) && (tx0 >= 4) && (tx0 + LG_TW + 4 <= W);
+    const bool fast = VEC && (tx0 >= 4) && (tx0 + LG_TW + 4 <= W);
     if (fast) {
         for (int idx = t; idx < DH * (DW / 4); idx += 256) {
             int er = idx / (DW / 4), g4 = idx % (DW / 4);
             int y = lg_reflect(ty0 - 3 + er, H);
             int x = tx0 - 4 + 4 * g4;
-            float4 d = *reinterpret_cast<const float4*>(depth + (size_t)y * W + x);
-            unsigned long long wbits = bits[(size_t)y * WW + (x >> 6)];
+            float4 d = *reinterpret_cast<const float4*>(depth + (unsigned)(y * W + x) * 4u);
+            unsigned long long wbits = bits_at(bits, y, x >> 6);
             unsigned nib = (unsigned)(wbits >> (x & 63)) & 0xfu;
             float4 o;
             o.x = (nib & 1u) ? d.x : 0.0f;
@@ -839,17 +895,37 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
             int er = idx / DW, ec = idx % DW;
             int y = lg_reflect(ty0 - 3 + er, H);
             int x = lg_reflect(tx0 - 4 + ec, W);
-            float d = depth[(size_t)y * W + x];
-            unsigned long long wbits = bits[(size_t)y * WW + (x >> 6)];
+            float d = *reinterpret_cast<const float*>(depth + (unsigned)(y * W + x) * 4u);
+            unsigned long long wbits = bits_at(bits, y, x >> 6);
             s_dm[idx] = ((wbits >> (x & 63)) & 1ull) ? d : 0.0f;
         }
     }
-    __syncthreads();
+    lg_lds_barrier();
+    if (ap->no_skip & 16) {   // ablation: the memory traffic of the dense path without its arithmetic
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) {
+            const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
+            if (y < H && x0 < W) {
+                const unsigned off = (unsigned)(y * W + x0);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = din_pre[rr][j] + s_dm[(tyi + 16 * rr + 3) * DW + 4 + 4 * txi + j] + (float)mnib_pre[rr] + (float)snib_pre[rr];
+                st4(LG_MAP_SDF, off, x0, v); st4(LG_MAP_APPROACH, off, x0, v); st4(LG_MAP_FLATNESS, off, x0, v);
+                st4(LG_MAP_ISOLATION, off, x0, v); st4(LG_MAP_ACCESS, off, x0, v); st4(LG_MAP_STEM, off, x0, v);
+                st4(LG_MAP_TRADITIONAL, off, x0, v);
+                if (!in_win) st4(LG_MAP_DISTANCE, off, x0, v);
+                st_valid(off, x0, 0u);
+            }
+        }
+        lg_lds_barrier();
+        continue;
+    }
     // ---- separable 5-tap Gaussian; g is stored at the *reflect-padded* coordinates the Sobel stage reads
     //      (F.pad(g,(1,1,1,1),'reflect'), grasp_point_selector.py:648): g_ext(e) = G(reflect1(e)).
     // Work split without div/mod: thread t owns column (t & 63) for rows (t >> 6) + 4k; the two extra halo
     // columns (64, 65) are covered by the first threads afterwards.
     {
+        const float k0 = ap->k1[0], k1 = ap->k1[1], k2 = ap->k1[2], k3 = ap->k1[3], k4 = ap->k1[4];
         const int ec = t & 63;
         int lc = lg_reflect(tx0 - 1 + ec, W) - (tx0 - 4);
         lc = lc < 2 ? 2 : (lc > DW - 3 ? DW - 3 : lc);
@@ -858,7 +934,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
             const int er = (t >> 6) + 4 * k;
             if (er < DH) {
                 const float* p = &s_dm[er * DW + lc - 2];
-                s_h[er * GW + ec] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+                s_h[er * GW + ec] = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4];
             }
         }
         if (t < 2 * DH) {
@@ -866,12 +942,9 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
             int lc2 = lg_reflect(tx0 - 1 + ec2, W) - (tx0 - 4);
             lc2 = lc2 < 2 ? 2 : (lc2 > DW - 3 ? DW - 3 : lc2);
             const float* p = &s_dm[er * DW + lc2 - 2];
-            s_h[er * GW + ec2] = a.k1[0] * p[0] + a.k1[1] * p[1] + a.k1[2] * p[2] + a.k1[3] * p[3] + a.k1[4] * p[4];
+            s_h[er * GW + ec2] = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4];
         }
-    }
-    __syncthreads();
-    {
-        const int ec = t & 63;
+        lg_lds_barrier();
 #pragma unroll
         for (int k = 0; k < (GH + 3) / 4; k++) {
             const int gr = (t >> 6) + 4 * k;
@@ -879,8 +952,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
                 int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
                 lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
                 const float* p = &s_h[(lr - 2) * GW + ec];
-                s_g[gr * (GW + 2) + ec] =
-                    a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+                s_g[gr * (GW + 2) + ec] = k0 * p[0] + k1 * p[GW] + k2 * p[2 * GW] + k3 * p[3 * GW] + k4 * p[4 * GW];
             }
         }
         if (t < 2 * GH) {
@@ -888,20 +960,24 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
             int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
             lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
             const float* p = &s_h[(lr - 2) * GW + ec2];
-            s_g[gr * (GW + 2) + ec2] =
-                a.k1[0] * p[0] + a.k1[1] * p[GW] + a.k1[2] * p[2 * GW] + a.k1[3] * p[3 * GW] + a.k1[4] * p[4 * GW];
+            s_g[gr * (GW + 2) + ec2] = k0 * p[0] + k1 * p[GW] + k2 * p[2 * GW] + k3 * p[3 * GW] + k4 * p[4 * GW];
         }
     }
-    __syncthreads();
+    lg_lds_barrier();
 
     // ---- per-pixel planes
-    const LgFrameParams fp = a.fp[frame];
-    const uint32_t mfi = a.maxfix[frame * 2 + 0], mfo = a.maxfix[frame * 2 + 1];
+    const __attribute__((address_space(4))) LgFrameParams* fpp = (const __attribute__((address_space(4))) LgFrameParams*)(ap->fp + frame);
+    const int has_angle = fpp->has_angle;
+    const float sin_t = fpp->sin_t, cos_t = fpp->cos_t;
+    const __attribute__((address_space(4))) uint32_t* mfp = (const __attribute__((address_space(4))) uint32_t*)(ap->maxfix + frame * 2);
+    const uint32_t mfi = mfp[0], mfo = mfp[1];
     const float maxabs = fmaxf((float)mfi * (1.0f / 65536.0f), (float)mfo * (1.0f / 65536.0f));
-    const float inv_maxabs = __frcp_rn(maxabs);
-    const float inv_2s2 = __frcp_rn(2.0f * a.optimal_distance * a.optimal_distance);
-    const float f2 = a.f * a.f;
-    const float ramp_step = (H > 1) ? (a.iso_ramp_bottom - a.iso_ramp_top) / (float)(H - 1) : 0.0f;
+    const float inv_maxabs = lg_uniform_f(__frcp_rn(maxabs));
+    const float opt_d = ap->optimal_distance;
+    const float inv_2s2 = ap->inv_2s2;
+    const float focal = ap->f;
+    const float f2 = focal * focal;
+    const float ramp_step = ap->iso_ramp_step;
     unsigned long long best = 0;
 #pragma unroll
     for (int rr = 0; rr < RPT; rr++) {
@@ -909,13 +985,18 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
         const int y = ty0 + ly;
         const int x0 = tx0 + 4 * txi;
         if (y < H && x0 < W) {
+            const unsigned off = (unsigned)(y * W + x0);
             const unsigned mnib = mnib_pre[rr], snib = snib_pre[rr];
             const float* din = din_pre[rr];
-            const float* g0 = &s_g[(ly + 0) * (GW + 2) + 4 * txi];
-            const float* g1 = g0 + (GW + 2);
-            const float* g2 = g1 + (GW + 2);
-            float ga[6], gb[6], gc[6];
-            {   // 16-byte + 8-byte LDS reads (row stride 272 B keeps them aligned): no bank conflicts
+            // flatness first: Sobel cross-correlation on the smoothed plane, exp(-5 |grad|) (:646-655); its 18 operands
+            // are dead before the other planes' arithmetic starts
+            float o_flat[4];
+            {
+                const float* g0 = &s_g[(ly + 0) * (GW + 2) + 4 * txi];
+                const float* g1 = g0 + (GW + 2);
+                const float* g2 = g1 + (GW + 2);
+                float ga[6], gb[6], gc[6];
+                // 16-byte + 8-byte LDS reads (row stride 272 B keeps them aligned): no bank conflicts
                 const float4 a4 = *reinterpret_cast<const float4*>(g0), b4 = *reinterpret_cast<const float4*>(g1),
                              c4 = *reinterpret_cast<const float4*>(g2);
                 const float2 a2 = *reinterpret_cast<const float2*>(g0 + 4), b2 = *reinterpret_cast<const float2*>(g1 + 4),
@@ -923,117 +1004,129 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
                 ga[0] = a4.x; ga[1] = a4.y; ga[2] = a4.z; ga[3] = a4.w; ga[4] = a2.x; ga[5] = a2.y;
                 gb[0] = b4.x; gb[1] = b4.y; gb[2] = b4.z; gb[3] = b4.w; gb[4] = b2.x; gb[5] = b2.y;
                 gc[0] = c4.x; gc[1] = c4.y; gc[2] = c4.z; gc[3] = c4.w; gc[4] = c2.x; gc[5] = c2.y;
+                const float flat_scale = ap->flat_scale;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float sx = (ga[j + 2] - ga[j]) + 2.0f * (gb[j + 2] - gb[j]) + (gc[j + 2] - gc[j]);
+                    float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
+                    o_flat[j] = __expf(-flat_scale * __builtin_amdgcn_sqrtf(sx * sx + sy * sy));  // v_sqrt_f32, 1 ulp
+                }
             }
-            const float dyp = (float)(y - a.cyi) - a.cyf;  // exact integer part first: no cancellation near the centre
-            const int dyb = min(y + 1, H - y);
-            const float ramp = a.iso_ramp_top + ramp_step * (float)y;
-            float o_sdf[4], o_app[4], o_flat[4], o_iso[4], o_acc[4], o_stem[4], o_trad[4];
+            st4(LG_MAP_FLATNESS, off, x0, o_flat);
+            if (!in_win) { const float z4[4] = {zero, zero, zero, zero}; st4(LG_MAP_DISTANCE, off, x0, z4); }
+            float o_trad[4];
             uint32_t vbytes = 0;
+            const float w_flat = ap->w_flat;
             // A leaf covers a few per cent of a frame: when no lane of this wave sits on the mask every plane but
             // flatness is exactly zero (they are all "* mask"), traditional = w_flat * flatness and nothing is
             // valid.  The wave-uniform branch skips the geometry / SDF / isolation arithmetic for those rows.
-            const bool wave_on_mask = (a.no_skip & 2) || __ballot(mnib != 0) != 0ull;
+            const bool wave_on_mask = (ap->no_skip & 2) || __ballot(mnib != 0) != 0ull;
+            if (wave_on_mask) {
+                float o_sdf[4], o_app[4], o_iso[4], o_acc[4], o_stem[4];
+                const float dyp = (float)(y - ap->cyi) - ap->cyf;  // exact integer part first: no cancellation near the centre
+                const int dyb = min(y + 1, H - y);
+                const float ramp = ap->iso_ramp_top + ramp_step * (float)y;
+                const float w_approach = ap->w_approach, w_sdf = ap->w_sdf, w_access = ap->w_access;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = x0 + j;
-                // flatness: Sobel cross-correlation on the smoothed plane, exp(-5 |grad|)   (:646-655)
-                float sx = (ga[j + 2] - ga[j]) + 2.0f * (gb[j + 2] - gb[j]) + (gc[j + 2] - gc[j]);
-                float sy = (gc[j] + 2.0f * gc[j + 1] + gc[j + 2]) - (ga[j] + 2.0f * ga[j + 1] + ga[j + 2]);
-                float flat = __expf(-a.flat_scale * __builtin_amdgcn_sqrtf(sx * sx + sy * sy));  // v_sqrt_f32, 1 ulp
-                float sdf = 0.0f, app = 0.0f, acc = 0.0f, iso = 0.0f, st = 0.0f, trad;
-                bool valid = false;
-                if (wave_on_mask) {
+                for (int j = 0; j < 4; j++) {
+                    const int x = x0 + j;
                     const float m = ((mnib >> j) & 1u) ? 1.0f : 0.0f;
-                    st = ((snib >> j) & 1u) ? 1.0f : 0.0f;
+                    const float st = ((snib >> j) & 1u) ? 1.0f : 0.0f;
                     // closed-form geometry planes                                           (:502-524, :569-593)
-                    const float dxp = (float)(x - a.cxi) - a.cxf;
+                    const float dxp = (float)(x - ap->cxi) - ap->cxf;
                     const float r2 = dxp * dxp + dyp * dyp;
                     const float inv_r = r2 > 0.0f ? rsqrtf(r2) : 0.0f;
                     const float r = r2 * inv_r;
-                    app = a.f * rsqrtf(r2 + f2) * m;
+                    const float app = focal * rsqrtf(r2 + f2) * m;
                     const float cosang = r2 > 0.0f ? dxp * inv_r : 1.0f;
-                    acc = (a.access_w_dist * (1.0f - r * a.inv_maxd) + a.access_w_dir * cosang) * m;
+                    const float acc = (ap->access_w_dist * (1.0f - r * ap->inv_maxd) + ap->access_w_dir * cosang) * m;
                     // SDF / edge term                                                        (:526-567)
-                    const float align = fp.has_angle ? fabsf(dxp * inv_r * fp.sin_t - dyp * inv_r * fp.cos_t) : 1.0f;
-                    const float dd = din[j] - a.optimal_distance;
+                    const float align = has_angle ? fabsf(dxp * inv_r * sin_t - dyp * inv_r * cos_t) : 1.0f;
+                    const float dd = din[j] - opt_d;
                     const float interior = __expf(-(dd * dd) * inv_2s2);
                     const float sdfn = din[j] * inv_maxabs;  // inside the mask d_out == 0
-                    sdf = (a.sdf_w_interior * interior + a.sdf_w_align * align + a.sdf_w_sdf * sdfn) * m;
+                    const float sdf = (ap->sdf_w_interior * interior + ap->sdf_w_align * align + ap->sdf_w_sdf * sdfn) * m;
                     // degenerate isolation map: chamfer-3 transform of an image with no zero pixel (:595-633)
                     const int dbrd = min(min(x + 1, W - x), dyb);
                     const float dt3 = (float)(LG_INIT0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
-                    const float s = dt3 * a.iso_inv_max;
-                    iso = (a.iso_w_close * s + a.iso_w_wide * s) * ramp * m;
+                    const float s = dt3 * ap->iso_inv_max;
+                    const float iso = (ap->iso_w_close * s + ap->iso_w_wide * s) * ramp * m;
                     // fusion + validity                                                      (:272-288)
-                    trad = (a.w_approach * app + a.w_sdf * sdf + a.w_flat * flat + a.w_access * acc) * (1.0f - st);
-                    valid = (din[j] > a.min_edge_distance) && (m > 0.0f) && (st < a.stem_valid_thresh);
-                } else {
-                    trad = a.w_flat * flat;  // (0.4*0 + 0.3*0 + 0.2*flat + 0.1*0) * (1 - 0), same float32 operations' result
+                    const float trad = (w_approach * app + w_sdf * sdf + w_flat * o_flat[j] + w_access * acc) * (1.0f - st);
+                    const bool valid = (din[j] > ap->min_edge_distance) && (m > 0.0f) && (st < ap->stem_valid_thresh);
+                    o_sdf[j] = sdf; o_app[j] = app; o_iso[j] = iso; o_acc[j] = acc; o_stem[j] = st; o_trad[j] = trad;
+                    if (valid) vbytes |= 1u << (8 * j);
+                    if (x < W) {
+                        unsigned long long key =
+                            ((unsigned long long)lg_orderable(valid ? trad : 0.0f) << 32) | (uint32_t)(y * W + x);
+                        best = key > best ? key : best;
+                    }
                 }
-                o_sdf[j] = sdf; o_app[j] = app; o_flat[j] = flat; o_iso[j] = iso; o_acc[j] = acc; o_stem[j] = st;
-                o_trad[j] = trad;
-                if (valid) vbytes |= 1u << (8 * j);
-                if (x < W) {
-                    unsigned long long key =
-                        ((unsigned long long)lg_orderable(valid ? trad : 0.0f) << 32) | (uint32_t)(y * W + x);
-                    best = key > best ? key : best;
-                }
-            }
-            const size_t off = fo + (size_t)y * W + x0;
-            auto st4 = [&](int mi, const float* v) {
-                float* dst = a.maps[mi];
-                if (!dst) return;
-                if (vec) {
-                    typedef float lg_f4 __attribute__((ext_vector_type(4)));
-                    lg_f4 pk = {v[0], v[1], v[2], v[3]};
-                    if (a.nt_stores) __builtin_nontemporal_store(pk, reinterpret_cast<lg_f4*>(dst + off));  // write-once stream
-                    else *reinterpret_cast<lg_f4*>(dst + off) = pk;
-                } else {
+                st4(LG_MAP_SDF, off, x0, o_sdf);
+                st4(LG_MAP_APPROACH, off, x0, o_app);
+                st4(LG_MAP_ISOLATION, off, x0, o_iso);
+                st4(LG_MAP_ACCESS, off, x0, o_acc);
+                st4(LG_MAP_STEM, off, x0, o_stem);
+            } else {
+                const float z4[4] = {zero, zero, zero, zero};
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (x0 + j < W) dst[off + j] = v[j];
+                for (int j = 0; j < 4; j++) {
+                    o_trad[j] = w_flat * o_flat[j];  // (0.4*0 + 0.3*0 + 0.2*flat + 0.1*0) * (1 - 0), same float32 operations' result
+                    if (x0 + j < W) {
+                        unsigned long long key = ((unsigned long long)lg_orderable(0.0f) << 32) | (uint32_t)(y * W + x0 + j);
+                        best = key > best ? key : best;
+                    }
                 }
-            };
-            st4(LG_MAP_SDF, o_sdf);
-            st4(LG_MAP_APPROACH, o_app);
-            st4(LG_MAP_FLATNESS, o_flat);
-            st4(LG_MAP_ISOLATION, o_iso);
-            st4(LG_MAP_ACCESS, o_acc);
-            st4(LG_MAP_STEM, o_stem);
-            st4(LG_MAP_TRADITIONAL, o_trad);
-            if (!in_win) { const float z4[4] = {0.f, 0.f, 0.f, 0.f}; st4(LG_MAP_DISTANCE, z4); }
-            if (a.valid) {
-                if (vec) {
-                    __builtin_nontemporal_store(vbytes, reinterpret_cast<uint32_t*>(a.valid + off));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (x0 + j < W) a.valid[off + j] = (uint8_t)((vbytes >> (8 * j)) & 1u);
-                }
+                st4(LG_MAP_SDF, off, x0, z4);
+                st4(LG_MAP_APPROACH, off, x0, z4);
+                st4(LG_MAP_ISOLATION, off, x0, z4);
+                st4(LG_MAP_ACCESS, off, x0, z4);
+                st4(LG_MAP_STEM, off, x0, z4);
             }
+            st4(LG_MAP_TRADITIONAL, off, x0, o_trad);
+            st_valid(off, x0, vbytes);
         }
     }
     best = lg_wave_max_u64(best);
     if ((t & 63) == 0) s_key[t >> 6] = best;
-    __syncthreads();
+    lg_lds_barrier();   // (also orders this tile's LDS reads before the next tile's writes)
     if (t == 0) {
         unsigned long long k = s_key[0];
         k = s_key[1] > k ? s_key[1] : k;
         k = s_key[2] > k ? s_key[2] : k;
         k = s_key[3] > k ? s_key[3] : k;
-        a.tilekeys[(size_t)frame * ntile + tile] = k;
+        ap->tilekeys[(size_t)frame * ntile + tile] = k;
     }
+    }   // tile walk
 }
 
 void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    long long total = (long long)a.tiles_x * a.tiles_y * a.B;
+    long long total = (long long)a.tiles_x * a.tiles_y * a.B;   // < 2^31: tiles_x * tiles_y <= 8192 (make_plan), B is an int count of frames that fit in memory
+    // LG_FINAL_PERSIST=n: n resident workgroups per CU walk the tiles instead of one workgroup per tile (a multiple of 8
+    // workgroups, so that blockIdx % 8 stays the XCD).  Measured (tools/final_persist_ab.sh, tools/final_ablate.sh): with every
+    // tile on the stencil path the walk is ~5 % faster at n = 8 (2.10 vs 2.21 ms per 128 frames; its arithmetic alone 1.14 vs
+    // 1.42 ms), but on real frames, where most tiles take the constant path, a fixed stride gives some workgroups more stencil
+    // tiles than others and the dispatcher's own load balancing wins (2.71 vs 3.12 ms per 256 frames): the default is 0.
+    static const int resident = [] {
+        int dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("LG_FINAL_PERSIST");
+        const int per_cu = e ? atoi(e) : 0;
+        return per_cu > 0 ? std::max(8, cus * per_cu / 8 * 8) : 0;
+    }();
+    const unsigned grid = (unsigned)((a.persist && resident && total > 2ll * resident) ? resident : total);
+    bool all = a.valid != nullptr;
+    for (int i = 0; i < LG_NUM_MAPS; i++) all = all && a.maps[i] != nullptr;
+    const bool vec = (a.W & 3) == 0;
+    auto k = vec ? (all ? lg_final_kernel<true, true> : lg_final_kernel<true, false>)
+                 : (all ? lg_final_kernel<false, true> : lg_final_kernel<false, false>);
     if (ev_start && ev_stop)  // events stamped by the command processor right around this dispatch
-        hipExtLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, ev_start, ev_stop, 0, a);
+        hipExtLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, a);
     else
-        hipLaunchKernelGGL(lg_final_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, a);
 }
 
-// ============================================================================ tile keys for an arbitrary (trad, valid) pair
 __global__ __launch_bounds__(256) void lg_tilekeys_kernel(const float* __restrict__ trad,
                                                           const uint8_t* __restrict__ valid,
                                                           unsigned long long* __restrict__ tilekeys, int H, int W,
