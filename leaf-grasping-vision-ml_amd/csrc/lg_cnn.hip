@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef LG_W4_EXP
 #define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
-#endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue
+#endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results)
 
 namespace {
 
@@ -901,6 +901,32 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                         for (int p = 0; p < 4; p++)
                             *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
                                 (f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)};
+                    }
+                    // The halo around the interior is (and stays) zero, and is written all the same: a cache line that keeps
+                    // bytes its writer did not touch leaves the L2 as a masked write, which the memory side has to merge with
+                    // the old line -- interior-only stores of layer 0's 1.6 GB took 0.81 ms, with the halo bytes 0.47 ms
+                    // (tools/ubench/partial_lines.hip).  Row ends by the first / last tile of a tile row, the top and bottom
+                    // rows (and corners) by the first / last tile row.  Only where it pays: layer 0 (32 x 32 output, 3 chunks per
+                    // item: store bound) 0.77 -> 0.47 ms; the deeper layers hide their stores behind the matrix work and the extra
+                    // single-lane store instructions cost them 0.01-0.10 ms each (16 x 16 and 8 x 8 maps are half edge tiles).
+                    if (OUT_HALO && !POOL && WI >= 32 && !(LG_W4_EXP & 128)) {
+                        typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+                        constexpr int TS = POOL ? 2 : 4;
+                        const bool hl = tcg == 0, hr = tcg == TC - 1;
+#pragma unroll
+                        for (int p = 0; p < TS; p++) {
+                            float* row = o + (TS * trg + p) * OP;
+                            if (hl) row[-1] = 0.f;
+                            if (hr) *reinterpret_cast<f32x3u*>(row + WO) = (f32x3u){0.f, 0.f, 0.f};
+                        }
+                        auto edge_row = [&](float* row) {
+                            if (POOL) *reinterpret_cast<f32x2u*>(row + 2 * tcg) = (f32x2u){0.f, 0.f};
+                            else *reinterpret_cast<f32x4u*>(row + 4 * tcg) = (f32x4u){0.f, 0.f, 0.f, 0.f};
+                            if (hl) row[-1] = 0.f;
+                            if (hr) *reinterpret_cast<f32x3u*>(row + WO) = (f32x3u){0.f, 0.f, 0.f};
+                        };
+                        if (trg == 0) edge_row(o - OP);
+                        if (trg == TC - 1) edge_row(o + WO * OP);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
