@@ -384,6 +384,14 @@ def main():
                 lib.lg_profile_enable(dsel._h, 0)
                 dbytes = FINAL_BYTES_PER_PX * nd * H * W
                 dach = dbytes / (ms_l.value / max(1, n_l.value) * 1e-3) / 1e9
+                ceiling = None   # the same loads / stores without arithmetic (tools/ubench/stream_mix.hip), a committed measurement
+                try:
+                    with open(os.path.join(REPO, "profiles", "r02_ubench_stream_mix.txt")) as fmix:
+                        for line in fmix:
+                            if line.startswith("tiled    64x16  same mix"):
+                                ceiling = float(line.split("(")[1].split()[0])
+                except (OSError, ValueError, IndexError):
+                    pass
                 traffic_d = None
                 try:
                     with open(os.path.join(REPO, "profiles", "r02_pmc_final_dense.json")) as fpmc:
@@ -395,7 +403,11 @@ def main():
                                          "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": traffic_d,
                                          "bytes_per_px": FINAL_BYTES_PER_PX, "frames_per_launch": nd, "launches": n_l.value,
                                          "avg_ms": round(ms_l.value / max(1, n_l.value), 4),
-                                         "masks": "labels >= 1 (all leaves, 20-30 % of the frame), LG_NO_SKIP=1"}
+                                         "masks": "labels >= 1 (all leaves, 20-30 % of the frame), LG_NO_SKIP=1",
+                                         "traffic_mix_ceiling_frac": ceiling,
+                                         "traffic_mix_ceiling": "profiles/r02_ubench_stream_mix.txt: a kernel with only this "
+                                                                "path's loads and stores (2 reads + 7 float planes + 1 byte plane "
+                                                                "per pixel, the same 64x16 tiles), measured on another run"}
                 dsel = dm = dd = None
             except Exception as e:  # noqa: BLE001
                 out["roofline_dense"] = {"error": str(e)}

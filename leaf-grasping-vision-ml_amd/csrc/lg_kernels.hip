@@ -1336,6 +1336,15 @@ __global__ __launch_bounds__(256) void lg_gather_kernel(const float* __restrict_
             const int i = t + 256 * q;
             outp[c * PL + (i >> 5) * RP + (i & 31)] = v[q];
         }
+        if (HALO && t < 200) {
+            // the plane's 200 halo floats, zero as they already are: a cache line the kernel writes only in part leaves
+            // the L2 as a masked write (tools/ubench/partial_lines.hip)
+            float* pl = outp + c * PL - O0;
+            const int hi = t < 72 ? (t < 36 ? t : 33 * 36 + (t - 36))              // top and bottom rows
+                                  : (t < 104 ? (t - 72 + 1) * 36                     // left column of rows 1..32
+                                             : ((t - 104) / 3 + 1) * 36 + 33 + (t - 104) % 3);   // columns 33..35
+            pl[hi] = 0.0f;
+        }
     }
 }
 

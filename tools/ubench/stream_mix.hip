@@ -4,6 +4,7 @@
 //   linear    each thread 4 consecutive pixels of the flattened batch, grid-stride (a wave = 1 KiB contiguous per plane)
 //   tiled     the kernel's shape: 64 x 16 pixel tiles, 256 threads, a wave = 4 rows x 256 B per plane, XCD-contiguous tile order
 //   tiled128  128 x 8 pixel tiles (a wave = 2 rows x 512 B)
+//   no byte plane: tiled 64 x 16 without the 1-byte plane (its 64-byte runs are half cache lines)
 //   writes    tiled, the nine stores only (the constant-tile path of the kernel)
 //   copy      linear, 2 reads + 1 write of 4 B (a plain streaming reference)
 // Prints ms and TB/s per variant (median of `reps` launches).
@@ -23,11 +24,12 @@ struct Planes { float* p[7]; uint8_t* valid; const float* depth; const float* di
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+template <bool VALID = true>
 __device__ __forceinline__ void emit(const Planes& P, size_t off, f4 a, f4 b, bool reads) {
     f4 v = reads ? a + b : (f4){1.f, 2.f, 3.f, 4.f};
 #pragma unroll
     for (int i = 0; i < 7; i++) *reinterpret_cast<f4*>(P.p[i] + off) = v + (float)i;
-    __builtin_nontemporal_store((uint32_t)(v.x > 0.5f ? 0x01010101u : 0u), reinterpret_cast<uint32_t*>(P.valid + off));
+    if (VALID) __builtin_nontemporal_store((uint32_t)(v.x > 0.5f ? 0x01010101u : 0u), reinterpret_cast<uint32_t*>(P.valid + off));
 }
 
 __global__ __launch_bounds__(256) void k_linear(Planes P, size_t npx) {
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void k_copy(Planes P, size_t npx) {
 }
 
 // TW x TH tiles, 256 threads x 4 pixels; resident workgroups walk an XCD-contiguous range (blockIdx % 8 = XCD)
-template <int TW, int TH, bool READS>
+template <int TW, int TH, bool READS, bool VALID = true>
 __global__ __launch_bounds__(256) void k_tiled(Planes P, int B, int H, int W) {
     static_assert(TW * TH == 1024, "256 threads x 4 pixels");
     const int tiles_x = W / TW, tiles_y = (H + TH - 1) / TH, ntile = tiles_x * tiles_y;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void k_tiled(Planes P, int B, int H, int W) {
         const size_t off = ((size_t)frame * H + y) * W + x;
         f4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
         if (READS) { a = *reinterpret_cast<const f4*>(P.depth + off); b = *reinterpret_cast<const f4*>(P.dist + off); }
-        emit(P, off, a, b, READS);
+        emit<VALID>(P, off, a, b, READS);
     }
 }
 
@@ -102,6 +104,7 @@ int main(int argc, char** argv) {
         {"tiled    64x16  same mix", 37.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<64, 16, true>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"tiled    128x8  same mix", 37.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<128, 8, true>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"tiled    256x4  same mix", 37.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<256, 4, true>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
+        {"tiled    64x16  no byte plane", 36.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<64, 16, true, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"writes   64x16  7W4 + 1W1", 29.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<64, 16, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"copy     2R + 1W4", 12.0, time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, P, npx); }, reps)},
     };
