@@ -63,7 +63,7 @@ struct lg_ctx {
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
-    hipEvent_t ev_orient = nullptr;
+    hipEvent_t ev_orient = nullptr, ev_side = nullptr;
     int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -74,6 +74,7 @@ struct lg_ctx {
     int opt_no_skip = 0;         // LG_NO_SKIP=1: lg_final_kernel without the constant-tile fast path (dense-path roofline);
                                  //            =3: also without the wave-level off-leaf shortcut
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
+    bool opt_side_tail = true;     // LG_SIDE_TAIL=0: frame-border maxima + stem bits after the sweeps on the caller's stream (round 1)
     bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
@@ -278,7 +279,8 @@ int lg_create(int device, lg_handle* out) {
         hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
         g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
@@ -309,6 +311,7 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e));
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
+    if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = atoi(e) != 0;
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
@@ -325,6 +328,7 @@ int lg_destroy(lg_handle h) {
     lg_leaf_free(h->leaf);
     lg_orient_free(h->orient);
     if (h->ev_orient) hipEventDestroy(h->ev_orient);
+    if (h->ev_side) hipEventDestroy(h->ev_side);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -392,6 +396,24 @@ struct Plan {  // one call's geometry, parameters and plane pointers (absolute, 
     uint8_t* valid;
 };
 
+// frame-border maxima of d_out + stem bits: both read only the bit rows, neither is needed before the plane kernel
+int enq_tail(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
+    const size_t words = (size_t)pl.H * pl.WW;
+    {
+        ProfScope ps(h, "dt_border", s);
+        lg_launch_dout_border(h->bits + off * words, h->win + off, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, pl.WW, s);
+    }
+    // (on the side stream both run before the bit-row export, which slows every concurrent memory-bound kernel 4x)
+    {
+        LgSeSpans se;
+        lg_make_se_spans(pl.P.stem_se, &se);
+        ProfScope ps(h, "stem", s);
+        lg_launch_stem_bits(h->bits + off * words, h->stem + off * words, n, pl.H, pl.W, pl.WW,
+                            pl.H - pl.H / pl.P.stem_bottom_div, se, s);
+    }
+    return LG_OK;
+}
+
 // pack bits + D2H of the bit rows on the copy stream
 int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_t ev_prep, hipEvent_t ev_copy) {
     const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
@@ -416,6 +438,11 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
                                  h->copy_stream));
         LG_HIP(h, hipEventRecord(h->ev_orient, h->copy_stream));
     }
+    if (h->opt_side_tail) {   // beside the sweeps (latency bound, two workgroups per CU), not behind them: 0.3 ms per 256 frames
+        const int rc = enq_tail(h, pl, off, n, h->copy_stream);
+        if (rc) return rc;
+        LG_HIP(h, hipEventRecord(h->ev_side, h->copy_stream));
+    }
     if (h->bits_host_dev)   // rows of the bounding boxes only, posted writes by a small grid on the priority stream
         lg_launch_export_rows(h->bits + off * words, h->win + off, h->bits_host_dev + off * words, n, pl.H, pl.WW, h->copy_stream);
     else
@@ -426,9 +453,9 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     return LG_OK;
 }
 
-// forward + backward distance sweeps, frame-border maxima, stem bits
+// forward + backward distance sweeps (+ frame-border maxima and stem bits when they do not run on the side stream)
 int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
-    const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
+    const size_t px = (size_t)pl.H * pl.W;
     {
         ProfScope ps(h, "dt_fwd", s);
         if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, h->win + off, n,
@@ -440,19 +467,7 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
         lg_launch_dt(true, pl.mask + off * px, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
                      h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, s);
     }
-    {
-        ProfScope ps(h, "dt_border", s);
-        lg_launch_dout_border(h->bits + off * words, h->win + off, h->maxfix + 2 * (size_t)off, n, pl.H, pl.W, pl.WW, s);
-    }
-    // the stem bits are only read by the fused plane kernel: after the sweeps, when the bit-row export (which slows every
-    // concurrent memory-bound kernel 4x) has drained
-    {
-        LgSeSpans se;
-        lg_make_se_spans(pl.P.stem_se, &se);
-        ProfScope ps(h, "stem", s);
-        lg_launch_stem_bits(h->bits + off * words, h->stem + off * words, n, pl.H, pl.W, pl.WW,
-                            pl.H - pl.H / pl.P.stem_bottom_div, se, s);
-    }
+    if (!h->opt_side_tail) return enq_tail(h, pl, off, n, s);
     return LG_OK;
 }
 
@@ -500,6 +515,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     const int H = pl.H, W = pl.W;
     const lg_params& P = pl.P;
     if (h->orient) LG_HIP(h, hipStreamWaitEvent(s, h->ev_orient, 0));   // fp_dev was written on the side stream
+    if (h->opt_side_tail) LG_HIP(h, hipStreamWaitEvent(s, h->ev_side, 0));  // maxfix (d_out border) and the stem bits
     if (upload_fp) LG_HIP(h, hipMemcpyAsync(h->fp_dev + off, h->fp_host + off, sizeof(LgFrameParams) * n, hipMemcpyHostToDevice, s));
     LgFinalArgs a;
     memset(&a, 0, sizeof(a));
