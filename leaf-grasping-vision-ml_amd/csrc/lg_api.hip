@@ -200,6 +200,8 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
         std::string err;
         const int rc = lg_orient_ensure(h->orient, nB, H, &err);
         if (rc) return fail(h, rc, err.c_str());
+    } else {
+        lg_orient_free(h->orient);   // (a scratch sized for another image height must not outlive it: host analysis from here on)
     }
     h->capB = nB; h->capH = H; h->capW = W; h->capK = nK;
     return LG_OK;

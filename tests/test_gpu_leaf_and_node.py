@@ -143,6 +143,29 @@ def test_leaf_many_labels(L):
     out = ols.leaf_statistics_batch(torch.from_numpy(np.stack([lab2, many])).cuda(), torch.from_numpy(np.stack([dep2, depth])).cuda())
     assert out[0] is not None and out[1] is None
     assert ols.select_optimal_leaf(torch.from_numpy(many).cuda(), torch.from_numpy(depth).cuda()) is None
+    # the native batched selection (lg_leaf_select_batch): a frame with >= 128 labels (numpy's summation order of the mean of
+    # medians changes there) or with more rows than the entry point reads back (330) takes the per-frame path, 1100 labels give
+    # None; the ordinary frames beside them are unaffected
+    lab3, dep3, _ = O.synthetic_scene(540, 720, 41)               # leaves above the 10000 px area threshold
+    crowded = lab3.copy()
+    k = 0
+    for y in range(2, 538, 12):
+        for x in range(2, 718, 12):
+            if k < 140 and not lab3[y:y + 3, x:x + 3].any():
+                crowded[y:y + 3, x:x + 3] = 1000 + k
+                k += 1
+    assert k == 140
+    grid = np.zeros((540, 720), np.int16); grid[:H, :W] = labels
+    many2 = np.zeros((540, 720), np.int16); many2[:H, :W] = many
+    dgrid = np.full((540, 720), 0.5, np.float32); dgrid[:H, :W] = depth
+    lab_b = torch.from_numpy(np.stack([lab3, crowded, grid, many2])).cuda()
+    dep_b = torch.from_numpy(np.stack([dep3, dep3, dgrid, dgrid])).cuda()
+    got = ols.select_optimal_leaves_batch(lab_b, dep_b)
+    want = [ols.select_optimal_leaf(lab_b[b], dep_b[b]) for b in range(4)]
+    assert got == want and got[0] is not None and got[1] is not None and got[3] is None
+    ref = O.RefOptimalLeafSelector()
+    ref.set_camera_params(np.array([[500.0, 0, 240, -20], [0, 500, 180, 0], [0, 0, 1, 0]]))
+    assert got[1] == ref.select_optimal_leaf(crowded, dep3)
 
 
 def test_clutter_argmax_branch_and_bound_adversarial(L):
