@@ -806,7 +806,6 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     if (!ap->no_skip) {
         if (t < 64) {
             unsigned long long nz = 0;
-#pragma unroll
             for (int e = t; e < DH * 3; e += 64) {
                 const int er = e / 3, wq = e % 3;                 // extended row, word (left neighbour, own, right neighbour)
                 const int y = lg_reflect(ty0 - 3 + er, H), wi = bx - 1 + wq;
@@ -1217,19 +1216,27 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         constexpr int CPT = LG_TW * LG_TH / LG_TOPK_T;
         const int chunks = naff * CPT;
         constexpr int GRP = 12;
+        // earlier picks whose suppression window reaches the affected tiles at all (usually the new pick and a neighbour or
+        // two): the per-pixel test below walks these, not all r + 1 picks -- at the late rounds that test was most of the round
+        unsigned long long rel = 0;
+        {
+            const int xlo = tx_lo * LG_TW, xhi = tx_hi * LG_TW + LG_TW - 1, ylo = ty_lo * LG_TH, yhi = ty_hi * LG_TH + LG_TH - 1;
+            for (int q = 0; q <= r; q++)
+                if (s_cx[q] + sup >= xlo && s_cx[q] - sup <= xhi && s_cy[q] + sup >= ylo && s_cy[q] - sup <= yhi) rel |= 1ull << q;
+        }
         for (int cb = 0; cb < chunks; cb += GRP) {
             float sc_[GRP];
-            int idx_[GRP], tile_[GRP];
+            int idx_[GRP], tile_[GRP], x_[GRP], y_[GRP];
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
                 const int c = cb + g;
-                sc_[g] = 0.0f; idx_[g] = -1; tile_[g] = 0;
+                sc_[g] = 0.0f; idx_[g] = -1; tile_[g] = 0; x_[g] = 0; y_[g] = 0;
                 if (c < chunks) {
                     const int ta = c / CPT;
                     const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
                     const int li = (c % CPT) * LG_TOPK_T + t;
                     const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
-                    tile_[g] = tile;
+                    tile_[g] = tile; x_[g] = x; y_[g] = y;
                     if (x < W && y < H) {
                         const size_t o = fo + (size_t)y * W + x;
                         idx_[g] = y * W + x;
@@ -1242,9 +1249,12 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
                 if (cb + g < chunks) {   // uniform across the workgroup
                     unsigned long long key = 0;
                     if (idx_[g] >= 0) {
-                        const int x = idx_[g] % W, y = idx_[g] / W;
+                        const int x = x_[g], y = y_[g];
                         bool dead = false;
-                        for (int q = 0; q <= r; q++) dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
+                        for (unsigned long long m = rel; m; m &= m - 1) {
+                            const int q = __builtin_ctzll(m);
+                            dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
+                        }
                         if (!dead) key = ((unsigned long long)lg_orderable(sc_[g]) << 32) | (uint32_t)idx_[g];
                     }
                     key = lg_wave_max_u64(key);
