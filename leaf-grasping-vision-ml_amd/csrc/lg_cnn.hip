@@ -25,6 +25,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// lg_wino4_kernel's DMA schedule: how many of a chunk's 9 + NIN transfers (U block of the next chunk first, then the input
+// rows three chunks ahead) a staging wave issues before the first MFMA group (S0) and after groups 0..3 (S1..S4; the rest after
+// group 4).  The U block has to land by the end of the chunk that issues it (2-stage ring, the LDS is full): issued three after
+// each of the first three groups (0 3 3 3 3) the last transfers had two thirds of a chunk to come back from L2 and the chunk's
+// closing wait stalled on them -- 5.26 ms per 5120 patches; 5 4 0 0 3: 5.06-5.12; all nine after group 0 (0 9 ...): 5.51 (they
+// delay the wave's own next group); all nine up front, inputs after group 3 (9 0 0 0 3): 5.04-5.06 (tools/cnn_time.py, one box).
+#ifndef LG_W4_S0
+#define LG_W4_S0 9
+#define LG_W4_S1 0
+#define LG_W4_S2 0
+#define LG_W4_S3 0
+#define LG_W4_S4 3
+#endif
 #ifndef LG_W4_EXP
 #define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
 #endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results)
@@ -807,8 +820,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
                     lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
                 } else {
-                    // the next chunk's U block (9 transfers), then the input NSTG chunks ahead (NIN transfers): three transfers after
-                    // each of the first MFMA groups
+                    // the next chunk's U block (9 transfers), then the input NSTG chunks ahead (NIN transfers); schedule: LG_W4_S*
                     const bool more = q + 1 < Q, more2 = q + NSTG < Q;
                     const float* ablk = U4 + (size_t)(c + 1 < NC ? cur.cob : cob_next) * ABLK + (size_t)(c + 1 < NC ? c + 1 : 0) * NCB * ABLK;
                     constexpr int NT = 9 + NIN;                  // transfers per chunk and staging wave
@@ -819,21 +831,24 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                             else if (more2) input_piece(k - 9, in_free);   // read by the transform of chunk q, one iteration ago
                         }
                     };
+                    // transfers (9 of U, then NIN of input) per slot: before the first MFMA group, then after groups 0..4
+                    constexpr int C0 = LG_W4_S0, C1 = C0 + LG_W4_S1, C2 = C1 + LG_W4_S2, C3 = C2 + LG_W4_S3, C4 = C3 + LG_W4_S4;
+                    xfer(0, C0);
                     LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
-                    xfer(0, 3);
+                    xfer(C0, C1);
                     LG_FRAG(3);
                     lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
-                    xfer(3, 6);
+                    xfer(C1, C2);
                     LG_FRAG(4);
                     lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
-                    xfer(6, 9);
+                    xfer(C2, C3);
                     LG_FRAG(5);
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
-                    xfer(9, 12);
+                    xfer(C3, C4);
                     LG_FRAG(6);
                     lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
-                    xfer(12, NT);
+                    xfer(C4, NT);
                     if (more2) input_advance();
                     LG_FRAG(7);
                     lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
