@@ -75,6 +75,7 @@ struct LgFinalArgs {
     int no_skip;    // 1: disable the off-mask fast path (LG_NO_SKIP=1, A/B measurements)
     int nt_stores;  // 0: plain stores (default); 1: non-temporal plane stores (LG_NT_STORES=1; measured slower)
     int persist;    // 1: resident workgroups walk the tiles (lg_launch_final); 0: one workgroup per tile
+    int tpw;        // > 0: consecutive tiles per workgroup (set by lg_launch_final)
 };
 
 // kernel launchers (lg_kernels.hip)

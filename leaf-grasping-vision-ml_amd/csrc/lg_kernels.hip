@@ -729,13 +729,17 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     const int xcd = (int)(blockIdx.x & 7u), tq = total >> 3, tr = total & 7;
     const int xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int xcd_count = tq + (xcd < tr ? 1 : 0);
-    const int stride = (int)((gridDim.x + 7u) >> 3);
-    int it = (int)(blockIdx.x >> 3);
-    if (it >= xcd_count) return;
+    // tiles per workgroup (ap->tpw > 0): workgroup j of the XCD takes the tpw consecutive tiles j * tpw ...; otherwise one tile
+    // each, or, as resident workgroups, tiles j, j + n, j + 2n ... of the XCD's range
+    const int tpw = ap->tpw;
+    const int stride = tpw > 0 ? 1 : (int)((gridDim.x + 7u) >> 3);
+    int it = (int)(blockIdx.x >> 3) * (tpw > 0 ? tpw : 1);
+    const int it_end = tpw > 0 ? min(it + tpw, xcd_count) : xcd_count;
+    if (it >= it_end) return;
     int frame = __builtin_amdgcn_readfirstlane((xcd_first + it) / ntile);
     int tile = xcd_first + it - frame * ntile;
     const int step_f = __builtin_amdgcn_readfirstlane(stride / ntile), step_t = stride - step_f * ntile;
-    for (int par = 0; it < xcd_count;
+    for (int par = 0; it < it_end;
          par ^= 1, it += stride, frame += step_f, tile += step_t, frame += (tile >= ntile ? 1 : 0), tile -= (tile >= ntile ? ntile : 0)) {
     asm volatile("" : "+s"(ap));
     int t = threadIdx.x;
@@ -1099,8 +1103,8 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     }   // tile walk
 }
 
-void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    long long total = (long long)a.tiles_x * a.tiles_y * a.B;   // < 2^31: tiles_x * tiles_y <= 8192 (make_plan), B is an int count of frames that fit in memory
+void lg_launch_final(const LgFinalArgs& a_in, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.B;   // < 2^31: tiles_x * tiles_y <= 8192 (make_plan), B is an int count of frames that fit in memory
     // LG_FINAL_PERSIST=n: n resident workgroups per CU walk the tiles instead of one workgroup per tile (a multiple of 8
     // workgroups, so that blockIdx % 8 stays the XCD).  Measured (tools/final_persist_ab.sh, tools/final_ablate.sh): with every
     // tile on the stencil path the walk is ~5 % faster at n = 8 (2.10 vs 2.21 ms per 128 frames; its arithmetic alone 1.14 vs
@@ -1114,7 +1118,15 @@ void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start, h
         const int per_cu = e ? atoi(e) : 0;
         return per_cu > 0 ? std::max(8, cus * per_cu / 8 * 8) : 0;
     }();
-    const unsigned grid = (unsigned)((a.persist && resident && total > 2ll * resident) ? resident : total);
+    // LG_FINAL_TPW=n: n consecutive tiles per workgroup (experiment: 2 / 4 / 8 change the benchmark launch by -1 / +1 / +3 %,
+    // the dense launch within the noise: the workgroup launch rate is not what limits either)
+    static const int tpw_env = getenv("LG_FINAL_TPW") ? atoi(getenv("LG_FINAL_TPW")) : 0;
+    LgFinalArgs a = a_in;
+    const bool walk = a.persist && resident && total > 2ll * resident;
+    a.tpw = walk ? 0 : std::max(0, tpw_env);
+    const long long per_xcd = (total + 7) / 8;
+    const unsigned grid = (unsigned)(walk ? resident : a.tpw > 1 ? 8 * ((per_xcd + a.tpw - 1) / a.tpw) : total);
+    if (a.tpw == 1) a.tpw = 0;
     bool all = a.valid != nullptr;
     for (int i = 0; i < LG_NUM_MAPS; i++) all = all && a.maps[i] != nullptr;
     const bool vec = (a.W & 3) == 0;
