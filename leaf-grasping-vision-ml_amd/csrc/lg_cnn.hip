@@ -725,6 +725,16 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 3; i++) col6(r[i], v[i]);
             if (LG_W4_EXP & 1) { v[0][0] = D(0, 0); v[1][1] = D(1, 1); v[2][2] = D(2, 2); }
+            // hipcc's SLP vectoriser seeds on the vector stores below and packs the column stage into v_pk_fma_f32 plus dozens of
+            // register moves per chunk; packed f32 issues at half rate here (tools/ubench/mfma_issue.hip), so the moves are pure
+            // cost on a SIMD whose every vector instruction adds to the MFMA time.  An opaque (empty, non-volatile) asm per value
+            // ends the vectoriser's use-def walk at the store operands: 5.24 -> 5.13 ms per 5120 patches (the row stage stays
+            // packed: its operand pairs are adjacent registers of the 16-byte loads, no moves).  Instantiating column stage and
+            // stores per half as well (no moves left in front of the stores) was SLOWER: 5.13 vs 4.96 ms on one box.
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) asm("" : "+v"(v[i][j]));
             if (th == 0) {      // positions 0..17
                 *reinterpret_cast<f32x4*>(g0) = (f32x4){v[0][0], v[0][1], v[0][2], v[0][3]};
                 *reinterpret_cast<f32x4*>(g0 + 256) = (f32x4){v[0][4], v[0][5], v[1][0], v[1][1]};
