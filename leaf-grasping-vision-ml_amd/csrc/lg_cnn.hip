@@ -673,9 +673,12 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             }
         };
         // transfer j (0..8) of the A block of (cob, chunk c): 2304 16-byte pieces = 9 x 4 waves x 64 lanes
+        const unsigned a_lane_off = 16u * (unsigned)(dw * 64 + lane);   // uniform base + one 32-bit lane offset: no address VALU per transfer
         auto a_piece = [&](int j, const float* ablk, int stage) {
             if (LG_W4_EXP & 4) return;
-            LG_DMA16(ablk + 4 * ((j * 4 + dw) * 64 + lane), s_a + stage * ABLK + 4 * ((j * 4 + dw) * 64));
+            const char* base = (const char*)(ablk + 4 * (j * 4 * 64));
+            asm("" : "+s"(base));   // (opaque: otherwise hipcc folds the lane offset into one 64-bit VGPR base and adds j * 4 KiB with a VALU op per transfer)
+            LG_DMA16(base + a_lane_off, s_a + stage * ABLK + 4 * ((j * 4 + dw) * 64));
         };
 
         // ---- transform state (waves 0..3): channel tk, tile tau, half th (rows 3 th .. 3 th + 2 of V)
