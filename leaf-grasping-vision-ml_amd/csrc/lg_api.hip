@@ -74,7 +74,8 @@ struct lg_ctx {
     int opt_no_skip = 0;         // LG_NO_SKIP=1: lg_final_kernel without the constant-tile fast path (dense-path roofline);
                                  //            =3: also without the wave-level off-leaf shortcut
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
-    bool opt_side_tail = true;     // LG_SIDE_TAIL=0: frame-border maxima + stem bits after the sweeps on the caller's stream (round 1)
+    int opt_side_tail = 1;         // LG_SIDE_TAIL=0: frame-border maxima + stem bits after the sweeps on the caller's stream (round 1); 1: on the
+                                   // side stream behind the orientation kernel; 2: on a third stream
     bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
@@ -313,7 +314,7 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e));
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
-    if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = atoi(e) != 0;
+    if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
@@ -440,10 +441,14 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
                                  h->copy_stream));
         LG_HIP(h, hipEventRecord(h->ev_orient, h->copy_stream));
     }
-    if (h->opt_side_tail) {   // beside the sweeps (latency bound, two workgroups per CU), not behind them: 0.3 ms per 256 frames
-        const int rc = enq_tail(h, pl, off, n, h->copy_stream);
+    if (h->opt_side_tail) {   // beside the sweeps (latency bound, two workgroups per CU), not behind them: 0.3 ms per 256 frames;
+        // LG_SIDE_TAIL=2 puts them on a third stream, so that orientation -> border -> stem is not one chain as long as the
+        // sweeps themselves -- measured slower (9.76-9.94 vs 9.56-9.77 ms per step, three alternating runs): default 1
+        hipStream_t ts = (h->opt_side_tail == 2 && h->opt_subbatch == 0) ? h->s_dt[1] : h->copy_stream;
+        if (ts != h->copy_stream) LG_HIP(h, hipStreamWaitEvent(ts, ev_prep, 0));
+        const int rc = enq_tail(h, pl, off, n, ts);
         if (rc) return rc;
-        LG_HIP(h, hipEventRecord(h->ev_side, h->copy_stream));
+        LG_HIP(h, hipEventRecord(h->ev_side, ts));
     }
     if (h->bits_host_dev)   // rows of the bounding boxes only, posted writes by a small grid on the priority stream
         lg_launch_export_rows(h->bits + off * words, h->win + off, h->bits_host_dev + off * words, n, pl.H, pl.WW, h->copy_stream);
