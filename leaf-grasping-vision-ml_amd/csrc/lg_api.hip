@@ -1,5 +1,5 @@
 // C-ABI of liblgrasp.so (see include/leafgrasp.h).  Host orchestration only: workspaces, streams,
-// the orientation hand-off, per-kernel event timing.  No exceptions cross the boundary.
+// the side-stream work beside the sweeps (orientation, border maxima, stem bits, bit-row export), per-kernel event timing.  No exceptions cross the boundary.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -7,8 +7,9 @@
 // every staging transfer is a `global_load_lds_dwordx4` (1 KiB per wave instruction).  Measured on MI355X
 // (tools/ubench/mfma_issue.hip, profiles/r02_ubench_mfma_f32_issue_costs.txt): the vector-memory path moves 64 B/clk/CU
 // with 16-byte lanes and 8 B/clk/CU with 4-byte lanes, whatever else the CU does -- the 4-byte staging of the first
-// version of these kernels kept that path busy for 44 % of a chunk's time.  The halos are written once (buffers are
-// zeroed at allocation, one buffer per layer) and never touched again: epilogues store interior pixels only.
+// version of these kernels kept that path busy for 44 % of a chunk's time.  The halos are zero from allocation on (one buffer per
+// layer) and stay zero: epilogues store the interior -- layer 0 also re-writes its (zero) halo bytes, so that no cache line of
+// its 1.6 GB output leaves the L2 partially written (see the epilogue of lg_wino4_kernel).
 //
 // Conv layers: out[n][co][y][x] = relu(b[co] + sum_{ky,kx,ci} w[ky][kx][ci][co] * in[n][ci][y+ky-1][x+kx-1]).
 // f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32) shares the SIMD's FMA lanes with the VALU: every other vector

@@ -37,7 +37,7 @@ struct LgWin {
     int bx0, bx1, by0, by1;  // bounding box of the mask (bx1 < bx0: empty mask -> window = whole frame)
 };
 
-struct LgFrameParams {  // per frame, written by the host after contour analysis
+struct LgFrameParams {  // per frame: leaf orientation, written by lg_orient_kernel (or by the host analysis for frames it hands back)
     float sin_t, cos_t;
     int has_angle;
     float theta;
