@@ -188,6 +188,14 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
 int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
                          double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, void* stream);
 
+/* The host half of lg_leaf_select_batch on its own (no device, no handle): the selection of leaf_scorer.py:53-203 from the rows
+   of lg_leaf_stats for ONE frame -- mean of medians -> tall leaves, the three scores of every candidate with area >= 10000,
+   Pareto filter on the tall (x 1.1) or the regular set, weighted pick.  *id: the chosen label, -1 = the reference's None, -2 =
+   128 or more leaves (numpy's summation order of the float32 mean changes there: the caller's own path decides).  tall
+   [tall_cap], *n_tall: get_tall_leaves() (*n_tall may exceed tall_cap; only tall_cap ids are written). */
+int lg_leaf_select_from_stats(const lg_leaf_stat* stats, int n, const int32_t* extrema, int H, int W, double cx, double cy,
+                              double f, int32_t* id, int32_t* tall, int tall_cap, int32_t* n_tall);
+
 /* GraspPointSelector.estimate_leaf_orientation (:718-752) for one frame: mask [H][W] u8 DEVICE.
    out (HOST, 5 floats): angle (rad, direction of the longer side of the min-area rectangle of the largest
    outer contour, in (0, pi]), major axis, minor axis, centre x, centre y.  Returns LG_OK and *found = 0

@@ -79,6 +79,9 @@ SYMBOLS = {
                                       C.POINTER(C.c_int), _VP]),
     "lg_leaf_select_batch": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, _VP]),
+    "lg_leaf_select_from_stats": (C.c_int, [C.POINTER(LgLeafStat), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_double,
+                                            C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                                            C.POINTER(C.c_int32)]),
     "lg_leaf_orientation": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _FP, C.POINTER(C.c_int), _VP]),
     "lg_profile_enable": (C.c_int, [_VP, C.c_int]),
     "lg_profile_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -772,6 +772,15 @@ int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth,
     return LG_OK;
 }
 
+int lg_leaf_select_from_stats(const lg_leaf_stat* stats, int n, const int32_t* extrema, int H, int W, double cx, double cy, double f,
+                              int32_t* id, int32_t* tall, int tall_cap, int32_t* n_tall) {
+    if (!stats || !extrema || !id || !tall || !n_tall || n < 0 || H < 1 || W < 1 || tall_cap < 1) return LG_ERR_INVALID;
+    int nt = 0;
+    *id = lg_leaf_select_host(stats, n, extrema, H, W, cx, cy, f, tall, tall_cap, &nt);
+    *n_tall = nt;
+    return LG_OK;
+}
+
 int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
     if (!h || !w) return LG_ERR_INVALID;
     LG_HIP(h, hipSetDevice(h->device));

@@ -18,6 +18,9 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
                       hipStream_t s, hipStream_t side, std::string* err);
 // statistics + the selection of leaf_scorer.py:53-181 for B frames in one call: ids [B] (-1: none; -2: a frame the caller
 // should take through the general path -- more than 256 labels or 128 leaves), n_tall [B], tall [B][tall_cap]
+// the selection of leaf_scorer.py:53-203 from one frame's statistics rows (host only); returns the label, -1 (none) or -2 (>= 128 leaves)
+int lg_leaf_select_host(const lg_leaf_stat* st, int n, const int32_t ext[4], int H, int W, double cx, double cy, double f,
+                        int32_t* tall, int tall_cap, int* n_tall);
 int lg_leaf_select_batch_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
                              double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, hipStream_t s, hipStream_t side,
                              std::string* err);
