@@ -525,3 +525,23 @@ def test_randomised_sweep_small(sel):
         mask = [(labels == 1), (labels >= 1), (labels == 1) | (rng.random((H, W)) > 0.995),
                 (labels == 2) | (labels == 3)][kind].astype(np.uint8)
         _compare_maps(sel, mask, depth, P)
+
+
+@pytest.mark.parametrize("env", [{"LG_FINAL_PERSIST": "8"}, {"LG_FINAL_PERSIST": "3"}, {"LG_FINAL_TPW": "4"}, {"LG_SIDE_TAIL": "0"},
+                                 {"LG_SIDE_TAIL": "2"}, {"LG_HOST_ORIENT": "1"}])
+def test_launch_forms_of_the_plane_kernel_give_the_same_planes(env):
+    """The plane kernel's other launch forms (resident workgroups walking the tiles, several consecutive tiles per workgroup) and
+    the other placements of the side work (border maxima + stem bits behind the sweeps / on a third stream, orientation on the
+    host) are A/B switches read once per process: each runs the planes-vs-oracle and end-to-end tests of this file in a process
+    of its own (odd image sizes, border tiles, empty masks, 1080p with the CNN)."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = ("test_score_maps_vs_oracle or test_score_maps_edge_cases or test_batch_equals_single or test_full_size_1080p_all_planes "
+           "or test_select_grasp_point_1080p_with_cnn_vs_oracle or test_candidates_vs_oracle_bit_exact")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(repo, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-k", sel], env=dict(os.environ, **env), cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
