@@ -59,6 +59,26 @@ __device__ __forceinline__ unsigned long long lg_wave_max_u64(unsigned long long
     lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
     return ((unsigned long long)hi << 32) | lo;
 }
+// (score, index) arg-max over the wave where the index grows with the lane: max of the 32-bit scores by DPP (12 instructions),
+// then the highest lane holding it -- a third of the instructions of the 64-bit key reduction above, same result as
+// max over (score << 32 | index).  Returns the key in every lane; all-zero scores give 0.
+__device__ __forceinline__ unsigned long long lg_wave_argmax_lane_ordered(uint32_t score, uint32_t index) {
+    uint32_t m = score;
+#define LG_MAX32_STEP(CTRL, RMASK) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, CTRL, RMASK, 0xf, false); m = o > m ? o : m; }
+    LG_MAX32_STEP(0x111, 0xf)  // row_shr:1
+    LG_MAX32_STEP(0x112, 0xf)  // row_shr:2
+    LG_MAX32_STEP(0x114, 0xf)  // row_shr:4
+    LG_MAX32_STEP(0x118, 0xf)  // row_shr:8
+    LG_MAX32_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1,3
+    LG_MAX32_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2,3
+#undef LG_MAX32_STEP
+    m = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+    if (m == 0) return 0ull;
+    const unsigned long long who = __ballot(score == m);
+    const int lane = 63 - __builtin_clzll(who);
+    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)index, lane);
+    return ((unsigned long long)m << 32) | idx;
+}
 __device__ __forceinline__ uint32_t lg_wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -1259,7 +1279,7 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
                 if (cb + g < chunks) {   // uniform across the workgroup
-                    unsigned long long key = 0;
+                    uint32_t score = 0;   // orderable(anything alive) >= 0x00800000 > 0: zero = suppressed / outside the image
                     if (idx_[g] >= 0) {
                         const int x = x_[g], y = y_[g];
                         bool dead = false;
@@ -1267,9 +1287,10 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
                             const int q = __builtin_ctzll(m);
                             dead |= (abs(x - s_cx[q]) <= sup) && (abs(y - s_cy[q]) <= sup);
                         }
-                        if (!dead) key = ((unsigned long long)lg_orderable(sc_[g]) << 32) | (uint32_t)idx_[g];
+                        if (!dead) score = lg_orderable(sc_[g]);
                     }
-                    key = lg_wave_max_u64(key);
+                    // within a chunk the flat index grows with the lane (li = chunk * 1024 + t): the cheaper lane-ordered arg-max
+                    const unsigned long long key = lg_wave_argmax_lane_ordered(score, (uint32_t)idx_[g]);
                     if ((t & 63) == 0 && key) atomicMax(&s_keys[tile_[g]], key);
                 }
             }
