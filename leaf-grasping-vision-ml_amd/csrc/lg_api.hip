@@ -553,7 +553,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     a.iso_ramp_step = (H > 1) ? (P.iso_ramp_bottom - P.iso_ramp_top) / (float)(H - 1) : 0.0f;
     gaussian1d(a.k1);
     a.no_skip = h->opt_no_skip;
-    a.persist = 1;
+    a.persist = 0;   // (lg_launch_final: the tile walk stays an experiment switch)
     a.nt_stores = h->opt_nt_stores ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
     {
         ProfScope ps(h, "final", s, true);

@@ -1125,24 +1125,26 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
 
 void lg_launch_final(const LgFinalArgs& a_in, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.B;   // < 2^31: tiles_x * tiles_y <= 8192 (make_plan), B is an int count of frames that fit in memory
-    // LG_FINAL_PERSIST=n: n resident workgroups per CU walk the tiles instead of one workgroup per tile (a multiple of 8
-    // workgroups, so that blockIdx % 8 stays the XCD).  Measured (tools/final_persist_ab.sh, tools/final_ablate.sh): with every
-    // tile on the stencil path the walk is ~5 % faster at n = 8 (2.10 vs 2.21 ms per 128 frames; its arithmetic alone 1.14 vs
-    // 1.42 ms), but on real frames, where most tiles take the constant path, a fixed stride gives some workgroups more stencil
-    // tiles than others and the dispatcher's own load balancing wins (2.71 vs 3.12 ms per 256 frames): the default is 0.
-    static const int resident = [] {
-        int dev = 0, cus = 256;
+    // Launch form.  One workgroup per tile by default: on real frames most tiles take the constant path and the dispatcher's
+    // own load balancing beats a fixed stride (2.71 vs 3.12 ms per 256 frames).  LG_FINAL_PERSIST=n (or a.persist): n resident
+    // workgroups per CU (a multiple of 8 workgroups, so that blockIdx % 8 stays the XCD) walk the tiles.  With every tile on
+    // the stencil path the walk measured 5 % faster on three boxes (2.10 vs 2.21 ms per 128 frames; its arithmetic alone 1.14
+    // vs 1.42 ms) and 25 % SLOWER on a fourth, faster one (2.28-2.33 vs 1.80-1.87 ms): a wave's loads for its next tile queue
+    // behind its own plane stores (vmcnt retires in order), which costs more the faster the memory side is.  Off by default.
+    static const int persist_env = getenv("LG_FINAL_PERSIST") ? atoi(getenv("LG_FINAL_PERSIST")) : -1;
+    static const int cus = [] {
+        int dev = 0, n = 256;
         hipGetDevice(&dev);
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const char* e = getenv("LG_FINAL_PERSIST");
-        const int per_cu = e ? atoi(e) : 0;
-        return per_cu > 0 ? std::max(8, cus * per_cu / 8 * 8) : 0;
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
     }();
+    const int per_cu = persist_env >= 0 ? persist_env : (a_in.persist ? LG_FINAL_WPE : 0);
+    const int resident = per_cu > 0 ? std::max(8, cus * per_cu / 8 * 8) : 0;
     // LG_FINAL_TPW=n: n consecutive tiles per workgroup (experiment: 2 / 4 / 8 change the benchmark launch by -1 / +1 / +3 %,
     // the dense launch within the noise: the workgroup launch rate is not what limits either)
     static const int tpw_env = getenv("LG_FINAL_TPW") ? atoi(getenv("LG_FINAL_TPW")) : 0;
     LgFinalArgs a = a_in;
-    const bool walk = a.persist && resident && total > 2ll * resident;
+    const bool walk = resident && total > 2ll * resident;
     a.tpw = walk ? 0 : std::max(0, tpw_env);
     const long long per_xcd = (total + 7) / 8;
     const unsigned grid = (unsigned)(walk ? resident : a.tpw > 1 ? 8 * ((per_xcd + a.tpw - 1) / a.tpw) : total);
