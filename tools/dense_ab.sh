@@ -1,3 +1,5 @@
+# A/B of the default launch form against LG_FINAL_PERSIST=0 through bench.py (headline launch and the dense leg), two rounds on one
+# box; prints frames/s, the plane kernel's ms and roofline fraction, the dense launch's ms and fraction.  usage (GPU box): bash tools/dense_ab.sh
 mkdir -p gpurun_out/r3e
 timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "not launch_forms" 2>&1 | tail -2
 for i in 1 2; do
