@@ -321,6 +321,15 @@ def test_orientation_device_equals_host(L, cap, monkeypatch):
         assert got[0] == pytest.approx(want[0], abs=2e-7), (k, got, want)
         assert got[1:] == want[1:], (k, got, want)
     assert n_found > 130
+    if cap is None:
+        # an image taller than the device analysis takes (16384 rows): the scratch is dropped, the host analysis answers; and
+        # back to an ordinary size afterwards
+        tall = np.zeros((16400, 64), np.uint8)
+        tall[100:16300, 10:30] = 1
+        tall[5000:5010, 30:50] = 1
+        assert dev.estimate_leaf_orientation(tall) == host.estimate_leaf_orientation(tall)
+        small = _orientation_cases()[2]
+        assert dev.estimate_leaf_orientation(small) == host.estimate_leaf_orientation(small)
 
 
 def test_orientation_in_the_batched_path(L, monkeypatch):
