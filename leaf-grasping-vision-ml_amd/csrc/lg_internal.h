@@ -18,7 +18,8 @@
 // ---- final-kernel tile
 #define LG_TW 64
 #ifndef LG_TH
-#define LG_TH 16   // measured at 1080p B=128: 16 -> 1.78 ms (0.69 of HBM peak), 32 -> 1.86 ms, 64 -> 2.11 ms
+#define LG_TH 16   // measured at 1080p B=128: 16 -> 1.78 ms (0.69 of HBM peak), 32 -> 1.86 ms, 64 -> 2.11 ms (round 1); round 2, whole library
+                   // built with -DLG_TH=32: planes 2.60-2.71 vs 2.66-2.74 ms per 256 frames, top-k 0.33 vs 0.27 ms, dense launch the same
 #endif
 
 // Window of the distance-transform sweeps (per frame, written by lg_bbox_kernel).  The binary leaf mask covers a few
