@@ -6,7 +6,8 @@
  * Plain pointers and sizes only; no torch types.  All image pointers are DEVICE pointers owned by
  * the caller (e.g. torch tensor.data_ptr()); frames are dense row-major [B][H][W].
  * Every entry point returns 0 (LG_OK) or a negative lg_status; nothing throws, nothing exits.
- * One handle <-> one device; calls on one handle are stream-ordered; handles are independent and
+ * One handle <-> one device; calls on one handle are stream-ordered, one at a time (a second thread entering the same
+ * handle gets LG_ERR_BUSY); handles are independent -- threads may drive different handles concurrently -- and
  * the library keeps no global mutable state (SURVEY.md 8b "Threading").
  *
  * Reference interfaces replaced (what a ctypes/cffi binding in the reference would call):
@@ -17,6 +18,7 @@
  *                      (scripts/utils/image_processor.py:56-64), _calculate_isolation_score :595-633,
  *                      cv2.distanceTransform :266, _calculate_accessibility_score :502-524,
  *                      _calculate_stem_penalty :688-701, estimate_leaf_orientation :718-752
+ *   lg_smooth_depth    ImageProcessor.smooth_depth (scripts/utils/image_processor.py:56-64)
  *   lg_topk_nms        GraspPointSelector._get_candidate_points  :447-482
  *   lg_gather_patches  get_ml_score feature assembly :59-127 + _extract_local_patch :392-445
  *   lg_cnn_load / lg_cnn_forward   GraspPointCNN.forward (eval)
@@ -44,7 +46,9 @@ typedef enum lg_status {
     LG_ERR_HIP = -2,      /* a HIP runtime call failed; see lg_last_error */
     LG_ERR_NOMEM = -3,
     LG_ERR_NO_MODEL = -4, /* lg_cnn_forward without lg_cnn_load (reference: ml_predictor is None) */
-    LG_ERR_UNSUPPORTED = -5
+    LG_ERR_UNSUPPORTED = -5,
+    LG_ERR_BUSY = -6      /* another thread is inside a call on this handle (one call in flight per handle; the error string
+                             of the running call is left alone) */
 } lg_status;
 
 /* Indices into out_maps[] -- the keys of the reference's `scores` dict
@@ -80,6 +84,9 @@ typedef struct lg_params {
     int32_t nms_min_distance;                       /* 10                         (:198)     */
     int32_t pregrasp_clearance;                     /* 15 px (SE 31)              (:777-778) */
     int32_t mask_is_bool;                           /* 1: torch.bool mask => border patches give no ML score */
+    int32_t gaussian_size;                          /* 5: the ImageProcessor's smoothing kernel that _calculate_flatness_map applies
+                                                       (:635-657, image_processor.py:25-32,56-64; sigma = size / 6).  1, 3, 5, 7;
+                                                       anything else => LG_ERR_UNSUPPORTED (an even size raises in the reference) */
 } lg_params;
 
 /* Raw GraspPointCNN(in_channels=9, attention_type, encoder_filters) state_dict tensors, HOST pointers,
@@ -143,6 +150,14 @@ void lg_default_params(lg_params* p);
 int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W,
                   const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
                   float* theta_host, void* stream);
+
+/* ImageProcessor.smooth_depth (scripts/utils/image_processor.py:56-64) on its own: reflect padding by gaussian_size / 2, then
+   the gaussian_size x gaussian_size kernel of _create_gaussian_kernel (:25-32, sigma = size / 6) applied as its two 1-D
+   factors.  depth [B][H][W] f32 DEVICE -> out [B][Ho][Wo] f32 DEVICE, Ho = H + 2 (size / 2) - size + 1 (= H for odd sizes,
+   H + 1 for even ones, as F.conv2d returns); 1 <= gaussian_size <= 15, gaussian_size / 2 < min(H, W).
+   lg_gaussian_taps: that 1-D factor (HOST, gaussian_size floats) -- what the plane kernel and lg_smooth_depth multiply with. */
+int lg_smooth_depth(lg_handle h, const float* depth, int B, int H, int W, int gaussian_size, float* out, void* stream);
+int lg_gaussian_taps(int gaussian_size, float* taps);
 
 /* Greedy spaced top-k on valid_scores = trad*valid (score desc, flat index desc on ties).
    out_xy [B][k][2] int32 (x,y) DEVICE, out_n [B] int32 DEVICE. */

@@ -6,19 +6,17 @@ include/leafgrasp.h).  There is no CPU / PyTorch fallback: a missing library rai
 and constructing a selector without a HIP device raises RuntimeError.
 """
 from ._lib import LIB_PATH, MAP_NAMES, LgError, lib  # noqa: F401  (loads the library, fails loudly)
+from ._lib import LgParams as ScoreParams  # every constant of the path (SURVEY Appendix A); defaults = the reference values
+from ._lib import default_params  # noqa: F401
 from .confidence_manager import ConfidenceManager
+from .data_collector import EnhancedGraspDataCollector
 from .grasp_point_selector import GraspPointSelector
+from .hybrid_grasp_selector import HybridGraspSelector
 from .hybrid_selector import HybridSelector
 from .image_processor import ImageProcessor
-from .params import ScoreParams, default_params
+from .leaf_scorer import OptimalLeafSelector
+from .node_harness import LeafGraspHarness
 
 __all__ = ["GraspPointSelector", "ImageProcessor", "HybridSelector", "ConfidenceManager", "ScoreParams",
-           "default_params", "MAP_NAMES", "LIB_PATH", "LgError"]
-try:
-    from .leaf_scorer import OptimalLeafSelector  # noqa: F401
-    from .hybrid_grasp_selector import HybridGraspSelector  # noqa: F401
-    from .node_harness import LeafGraspHarness  # noqa: F401
-    from .data_collector import EnhancedGraspDataCollector  # noqa: F401
-    __all__ += ["OptimalLeafSelector", "HybridGraspSelector", "LeafGraspHarness", "EnhancedGraspDataCollector"]
-except ImportError:  # modules of later build steps
-    pass
+           "default_params", "MAP_NAMES", "LIB_PATH", "LgError", "OptimalLeafSelector", "HybridGraspSelector",
+           "LeafGraspHarness", "EnhancedGraspDataCollector"]

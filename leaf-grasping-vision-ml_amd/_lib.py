@@ -11,7 +11,7 @@ MAP_NAMES = ("sdf_score", "approach_score", "flatness_map", "isolation_map", "di
              "accessibility_map", "stem_penalty", "traditional_score")  # grasp_point_selector.py:258-280
 MAP_INDEX = {n: i for i, n in enumerate(MAP_NAMES)}
 
-LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_NOMEM, LG_ERR_NO_MODEL, LG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_NOMEM, LG_ERR_NO_MODEL, LG_ERR_UNSUPPORTED, LG_ERR_BUSY = 0, -1, -2, -3, -4, -5, -6
 
 
 class LgParams(C.Structure):
@@ -20,7 +20,7 @@ class LgParams(C.Structure):
         "sdf_w_sdf", "optimal_distance", "access_w_dist", "access_w_dir", "flat_scale", "iso_w_close",
         "iso_w_wide", "iso_ramp_top", "iso_ramp_bottom", "min_edge_distance", "stem_valid_thresh")] + \
         [(n, C.c_int32) for n in ("stem_se", "stem_bottom_div", "top_k", "nms_min_distance",
-                                  "pregrasp_clearance", "mask_is_bool")]
+                                  "pregrasp_clearance", "mask_is_bool", "gaussian_size")]
 
 
 _FP = C.POINTER(C.c_float)
@@ -64,6 +64,8 @@ SYMBOLS = {
     "lg_default_params": (None, [C.POINTER(LgParams)]),
     "lg_score_maps": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(LgParams),
                                 C.POINTER(_VP * LG_NUM_MAPS), _VP, _FP, _VP]),
+    "lg_smooth_depth": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "lg_gaussian_taps": (C.c_int, [C.c_int, _FP]),
     "lg_topk_nms": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "lg_gather_patches": (C.c_int, [_VP, _VP, _VP, C.POINTER(_VP * LG_NUM_MAPS), C.c_int, C.c_int, C.c_int,
                                     C.c_int, _VP, _VP, _VP, _VP]),
@@ -128,6 +130,8 @@ class LgError(RuntimeError):
 
 
 def check(handle, rc, what):
+    if rc == LG_ERR_BUSY:
+        raise LgError(f"{what}: another thread is inside a call on this handle (one call in flight per selector instance)")
     if rc != LG_OK:
         msg = lib.lg_last_error(handle if handle else None).decode()   # NULL handle: the reason lg_create failed
         raise LgError(f"{what} failed with status {rc}: {msg}")

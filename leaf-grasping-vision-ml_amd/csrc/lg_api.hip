@@ -76,6 +76,8 @@ struct lg_ctx {
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
     int opt_side_tail = 1;         // LG_SIDE_TAIL=0: frame-border maxima + stem bits after the sweeps on the caller's stream (round 1); 1: on the
                                    // side stream behind the orientation kernel; 2: on a third stream
+    std::string orient_note;       // why the device-side orientation scratch could not be set up (host analysis is used then)
+    std::atomic<bool> busy{false}; // one call in flight per handle (SURVEY 8b "Threading"): a concurrent second call gets LG_ERR_BUSY
     bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
@@ -98,6 +100,20 @@ int fail(lg_handle h, int code, const char* what, hipError_t e = hipSuccess) {
         hipError_t e_ = (call);                                            \
         if (e_ != hipSuccess) return fail(h, LG_ERR_HIP, #call, e_);       \
     } while (0)
+
+// One call in flight per handle: the workspace, the profiling slots and the error string belong to the call that holds the
+// flag.  rospy runs every subscriber callback on its own thread and the reference node guards itself with a plain bool
+// (leaf_grasp_node_v3.py:104-107); here a concurrent second call on the SAME handle returns LG_ERR_BUSY without touching
+// anything (handles are independent: different handles run side by side).
+struct BusyGuard {
+    lg_ctx* h;
+    bool ok;
+    explicit BusyGuard(lg_ctx* h_) : h(h_), ok(!h_->busy.exchange(true, std::memory_order_acquire)) {}
+    ~BusyGuard() { if (ok) h->busy.store(false, std::memory_order_release); }
+};
+#define LG_ENTER(h)        \
+    BusyGuard busy_guard_(h); \
+    if (!busy_guard_.ok) return LG_ERR_BUSY
 
 struct ProfScope {  // records an event pair around a launch when profiling is on
     lg_ctx* h;
@@ -198,9 +214,10 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, hipHostMalloc((void**)&h->h_info, sizeof(float) * nB * nK * 2));
     LG_HIP(h, hipHostMalloc((void**)&h->h_logits, sizeof(float) * nB * nK));
     if (!h->opt_host_orient && H <= 16384 && W <= 8192) {
+        // no device-side scratch (allocation, or the LDS request on a part with less of it): the host contour analysis of
+        // every frame is a complete path of its own -- scoring goes on, the reason stays readable in orient_note
         std::string err;
-        const int rc = lg_orient_ensure(h->orient, nB, H, &err);
-        if (rc) return fail(h, rc, err.c_str());
+        if (lg_orient_ensure(h->orient, nB, H, &err)) { h->orient_note = err; lg_orient_free(h->orient); }
     } else {
         lg_orient_free(h->orient);   // (a scratch sized for another image height must not outlive it: host analysis from here on)
     }
@@ -218,11 +235,14 @@ int ensure_ws_map(lg_ctx* h, int i) {  // internal plane when the caller does no
     return LG_OK;
 }
 
-void gaussian1d(float k1[5]) {  // ImageProcessor._create_gaussian_kernel, size 5, sigma = 5/6 (image_processor.py:25-32)
-    const double sigma = 5.0 / 6.0;
-    double e[5], s = 0;
-    for (int i = 0; i < 5; i++) { e[i] = exp(-((i - 2) * (i - 2)) / (2 * sigma * sigma)); s += e[i]; }
-    for (int i = 0; i < 5; i++) k1[i] = (float)(e[i] / s);
+// ImageProcessor._create_gaussian_kernel (image_processor.py:25-32): the 2-D kernel exp(-(dx^2 + dy^2) / 2 sigma^2) / sum with
+// sigma = size / 6 is the outer product of this 1-D factor with itself
+void gaussian1d(int size, float* k1) {
+    const double sigma = size / 6.0;
+    const int c = size / 2;
+    double e[LG_MAX_GAUSS], s = 0;
+    for (int i = 0; i < size; i++) { e[i] = exp(-((i - c) * (i - c)) / (2 * sigma * sigma)); s += e[i]; }
+    for (int i = 0; i < size; i++) k1[i] = (float)(e[i] / s);
 }
 
 void parallel_for(lg_ctx* h, int n, const std::function<void(int)>& fn) {
@@ -253,6 +273,7 @@ void lg_default_params(lg_params* p) {
     p->top_k = 20; p->nms_min_distance = 10;
     p->pregrasp_clearance = 15;
     p->mask_is_bool = 1;
+    p->gaussian_size = 5;   // the node's ImageProcessor(..., gaussian_kernel_size=5) (leaf_grasp_node_v3.py:37,66-67)
 }
 
 static thread_local std::string g_create_err = "null handle";
@@ -311,7 +332,7 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_HOST_THREADS")) h->host_threads = std::max(1, atoi(e));
     if (const char* e = getenv("LG_SUBBATCH")) h->opt_subbatch = std::max(1, atoi(e));
     h->opt_trace = getenv("LG_TRACE") != nullptr;
-    if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e));
+    if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e)) & 3;   // (both bits leave the results unchanged)
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
@@ -322,6 +343,7 @@ int lg_create(int device, lg_handle* out) {
 
 int lg_destroy(lg_handle h) {
     if (!h) return LG_ERR_INVALID;
+    if (h->busy.exchange(true, std::memory_order_acquire)) return LG_ERR_BUSY;   // a call is running on another thread
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     delete h->pool;
@@ -349,6 +371,7 @@ const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : g_create_er
 
 int lg_profile_enable(lg_handle h, int on) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     for (auto& p : h->prof) { p.used = 0; p.launches = 0; p.total_ms = 0.0; }
     h->prof_on = on < 0 ? 0 : on;
     return LG_OK;
@@ -356,6 +379,7 @@ int lg_profile_enable(lg_handle h, int on) {
 
 int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_ms) {
     if (!h || !name) return LG_ERR_INVALID;
+    LG_ENTER(h);
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     prof_flush(h);
@@ -372,6 +396,7 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
 
 int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]) {
     if (!h || !out || frame < 0 || frame >= h->capB || !h->maxfix) return LG_ERR_INVALID;
+    LG_ENTER(h);
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (hipMemcpy(out, h->maxfix + 2 * (size_t)frame, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
@@ -551,7 +576,8 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     a.inv_maxd = (float)(1.0 / sqrt((double)W * W + (double)H * H));
     a.inv_2s2 = 1.0f / (2.0f * P.optimal_distance * P.optimal_distance);   // (correctly rounded, like the device's __frcp_rn)
     a.iso_ramp_step = (H > 1) ? (P.iso_ramp_bottom - P.iso_ramp_top) / (float)(H - 1) : 0.0f;
-    gaussian1d(a.k1);
+    gaussian1d(P.gaussian_size, a.k1);
+    a.gauss_r = P.gaussian_size / 2;
     a.no_skip = h->opt_no_skip;
     a.persist = 0;   // (lg_launch_final: the tile walk stays an experiment switch)
     a.nt_stores = h->opt_nt_stores ? 1 : 0;  // measured: non-temporal plane stores are slower here (0.57 vs 0.50 ms)
@@ -571,6 +597,10 @@ int make_plan(lg_ctx* h, Plan& pl, const float* depth, const uint8_t* mask, int 
         return fail(h, LG_ERR_INVALID, "stem_se must be in [1,64], stem_bottom_div >= 1");
     if (pl.P.nms_min_distance < 0 || pl.P.pregrasp_clearance < 0 || pl.P.pregrasp_clearance > 31)
         return fail(h, LG_ERR_INVALID, "nms_min_distance must be >= 0, pregrasp_clearance in [0,31]");
+    // _calculate_flatness_map smooths with the caller's ImageProcessor (grasp_point_selector.py:635-657): an even size gives
+    // an (H+1) x (W+1) plane there and the fusion raises -> None triple; odd sizes above 7 exceed this kernel's halo
+    if (pl.P.gaussian_size < 1 || pl.P.gaussian_size > 7 || (pl.P.gaussian_size & 1) == 0)
+        return fail(h, LG_ERR_UNSUPPORTED, "gaussian_size must be 1, 3, 5 or 7 (an even size fails in the reference too: shape mismatch in the fusion)");
     pl.B = B; pl.H = H; pl.W = W; pl.WW = (W + 63) / 64;
     pl.tiles_x = (W + LG_TW - 1) / LG_TW; pl.tiles_y = (H + LG_TH - 1) / LG_TH;
     if (pl.tiles_x * pl.tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "image too large for the top-k tile table");
@@ -587,6 +617,7 @@ extern "C" {
 int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
                   float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, float* theta_host, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     Plan pl;
     int rc = make_plan(h, pl, depth, mask, B, H, W, pin, out_maps, out_valid, "lg_score_maps");
     if (rc) return rc;
@@ -617,9 +648,31 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
     return LG_OK;
 }
 
+int lg_smooth_depth(lg_handle h, const float* depth, int B, int H, int W, int gaussian_size, float* out, void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    if (!depth || !out || B < 1 || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_smooth_depth: bad argument");
+    if (gaussian_size < 1 || gaussian_size > LG_MAX_GAUSS) return fail(h, LG_ERR_UNSUPPORTED, "lg_smooth_depth: gaussian_size must be in [1,15]");
+    if (gaussian_size / 2 >= std::min(H, W))   // torch: "Padding size should be less than the corresponding input dimension"
+        return fail(h, LG_ERR_INVALID, "lg_smooth_depth: reflect padding (gaussian_size / 2) must be smaller than H and W");
+    LG_HIP(h, hipSetDevice(h->device));
+    LgGaussTaps taps;
+    memset(&taps, 0, sizeof(taps));
+    gaussian1d(gaussian_size, taps.k);
+    lg_launch_smooth(depth, out, B, H, W, gaussian_size, taps, (hipStream_t)stream_);
+    LG_HIP(h, hipGetLastError());
+    return LG_OK;
+}
+
+int lg_gaussian_taps(int gaussian_size, float* taps) {
+    if (!taps || gaussian_size < 1 || gaussian_size > LG_MAX_GAUSS) return LG_ERR_INVALID;
+    gaussian1d(gaussian_size, taps);
+    return LG_OK;
+}
+
 int lg_topk_nms(lg_handle h, const float* trad, const uint8_t* valid, int B, int H, int W, int k, int min_dist,
                 int32_t* out_xy, int32_t* out_n, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!trad || !valid || !out_xy || !out_n || B <= 0 || H < 1 || W < 1 || k < 1 || k > 64 || min_dist < 0)
         return fail(h, LG_ERR_INVALID, "lg_topk_nms: bad argument (1 <= k <= 64)");
     hipStream_t s = (hipStream_t)stream_;
@@ -637,6 +690,7 @@ int lg_topk_nms(lg_handle h, const float* trad, const uint8_t* valid, int B, int
 int lg_gather_patches(lg_handle h, const float* depth, const uint8_t* mask, const float* const maps[LG_NUM_MAPS], int B,
                       int H, int W, int k, const int32_t* xy, const int32_t* n, float* patches, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!depth || !mask || !maps || !xy || !n || !patches || B <= 0 || k < 1)
         return fail(h, LG_ERR_INVALID, "lg_gather_patches: bad argument");
     for (int i = 0; i < 7; i++)
@@ -653,6 +707,7 @@ int lg_harvest_patches(lg_handle h, const float* depth, const uint8_t* mask, con
                        int W, int n, const int32_t* xy, const int32_t* rot, float* out_depth, float* out_mask,
                        float* out_scores, int32_t* flags, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!depth || !mask || !maps || !xy || !out_depth || !out_mask || !out_scores || !flags || n < 1 || H < 32 || W < 32)
         return fail(h, LG_ERR_INVALID, "lg_harvest_patches: bad argument");
     for (int i = 0; i < 7; i++)
@@ -667,6 +722,7 @@ int lg_harvest_patches(lg_handle h, const float* depth, const uint8_t* mask, con
 int lg_negative_masks(lg_handle h, const float* distance_map, const uint8_t* mask, int H, int W, uint8_t* out_tip,
                       uint8_t* out_stem, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!distance_map || !mask || !out_tip || !out_stem || H < 1 || W < 1)
         return fail(h, LG_ERR_INVALID, "lg_negative_masks: bad argument");
     hipStream_t s = (hipStream_t)stream_;
@@ -681,6 +737,7 @@ int lg_negative_masks(lg_handle h, const float* distance_map, const uint8_t* mas
 
 int lg_leaf_contour(lg_handle h, const uint8_t* mask, int H, int W, int32_t* out_xy, int cap, int* n_out, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!mask || !n_out || (cap > 0 && !out_xy) || cap < 0 || H < 1 || W < 1)
         return fail(h, LG_ERR_INVALID, "lg_leaf_contour: bad argument");
     hipStream_t s = (hipStream_t)stream_;
@@ -700,6 +757,7 @@ int lg_leaf_contour(lg_handle h, const uint8_t* mask, int H, int W, int32_t* out
 
 int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* out, int* found, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!mask || !out || !found || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_leaf_orientation: bad argument");
     hipStream_t s = (hipStream_t)stream_;
     LG_HIP(h, hipSetDevice(h->device));
@@ -730,6 +788,7 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
 int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
                   lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!labels || !depth || !stats || !n_leaves || !extrema || H < 1 || W < 1 || max_leaves < 1)
         return fail(h, LG_ERR_INVALID, "lg_leaf_stats: bad argument");
     hipStream_t s = (hipStream_t)stream_;
@@ -745,6 +804,7 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
                         float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
                         void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!labels || !depth || !stats || !n_leaves || !extrema || !status || B < 1 || H < 1 || W < 1 || max_leaves < 1)
         return fail(h, LG_ERR_INVALID, "lg_leaf_stats_batch: bad argument");
     hipStream_t s = (hipStream_t)stream_;
@@ -760,14 +820,21 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
 int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
                          double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!labels || !depth || !ids || !n_tall || !tall || B < 1 || H < 1 || W < 1 || tall_cap < 1)
         return fail(h, LG_ERR_INVALID, "lg_leaf_select_batch: bad argument");
     hipStream_t s = (hipStream_t)stream_;
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     ProfScope ps(h, "leaf", s);
-    int rc = lg_leaf_select_batch_run(h->leaf, labels, depth, B, H, W, cx, cy, f, ids, n_tall, tall, tall_cap, s,
-                                      h->s_dt[0], &err);
+    int rc;
+    try {   // (the host half allocates: nothing may throw across the C boundary)
+        rc = lg_leaf_select_batch_run(h->leaf, labels, depth, B, H, W, cx, cy, f, ids, n_tall, tall, tall_cap, s, h->s_dt[0], &err);
+    } catch (const std::bad_alloc&) {
+        return fail(h, LG_ERR_NOMEM, "lg_leaf_select_batch: out of host memory");
+    } catch (...) {
+        return fail(h, LG_ERR_INVALID, "lg_leaf_select_batch: unexpected exception");
+    }
     if (rc) return fail(h, rc, err.c_str());
     return LG_OK;
 }
@@ -776,13 +843,20 @@ int lg_leaf_select_from_stats(const lg_leaf_stat* stats, int n, const int32_t* e
                               int32_t* id, int32_t* tall, int tall_cap, int32_t* n_tall) {
     if (!stats || !extrema || !id || !tall || !n_tall || n < 0 || H < 1 || W < 1 || tall_cap < 1) return LG_ERR_INVALID;
     int nt = 0;
-    *id = lg_leaf_select_host(stats, n, extrema, H, W, cx, cy, f, tall, tall_cap, &nt);
+    try {
+        *id = lg_leaf_select_host(stats, n, extrema, H, W, cx, cy, f, tall, tall_cap, &nt);
+    } catch (const std::bad_alloc&) {
+        return LG_ERR_NOMEM;
+    } catch (...) {
+        return LG_ERR_INVALID;
+    }
     *n_tall = nt;
     return LG_OK;
 }
 
 int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
     if (!h || !w) return LG_ERR_INVALID;
+    LG_ENTER(h);
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     int rc = lg_cnn_upload(&h->cnn, w, &err);
@@ -792,6 +866,7 @@ int lg_cnn_load(lg_handle h, const lg_cnn_weights* w) {
 
 int lg_cnn_unload(lg_handle h) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     lg_cnn_free(&h->cnn);
@@ -800,6 +875,7 @@ int lg_cnn_unload(lg_handle h) {
 
 int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!patches || !logits || N <= 0) return fail(h, LG_ERR_INVALID, "lg_cnn_forward: bad argument");
     if (!h->cnn.loaded) return fail(h, LG_ERR_NO_MODEL, "lg_cnn_forward: no model loaded (reference: ml_predictor is None)");
     hipStream_t s = (hipStream_t)stream_;
@@ -815,6 +891,7 @@ int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void
 int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
                     float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, lg_grasp_result* results, void* stream_) {
     if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
     if (!results) return fail(h, LG_ERR_INVALID, "lg_select_grasp: results is null");
     Plan pl;
     int rc = make_plan(h, pl, depth, mask, B, H, W, pin, out_maps, out_valid, "lg_select_grasp");

@@ -1399,9 +1399,10 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         x = c->in_halo;
     }
     // layer 0: the F(4x4,3x3) kernel on 12 input planes (3 chunks); the direct 9-channel kernel with LG_CNN_DIRECT / _F23 / mask bit 0 clear
-    if (!c->use_f23 && (c->wino_mask & 1))
-        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, s);
-    else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
+    if (!c->use_f23 && (c->wino_mask & 1) &&
+        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, s)) {
+        // (a shape the F(4x4) table lacks falls through to the direct kernel instead of leaving act[0] unwritten)
+    } else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
     else launch_conv0<128>(x, c, c->act[0], N, s);
     const float* cur = c->act[0];
     if (c->standard) {

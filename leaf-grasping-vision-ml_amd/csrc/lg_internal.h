@@ -15,6 +15,9 @@
 #define LG_INF 0x3FFFFFFFu    // "no path yet" inside the DT sweeps (never wins against a real distance)
 #define LG_NOSRC 0x20000000u  // values >= this after the backward sweep mean: image has no source pixel
 
+#define LG_MAX_GAUSS 15   // largest smoothing kernel lg_smooth_depth takes (the fused plane kernel: 1, 3, 5, 7)
+struct LgGaussTaps { float k[LG_MAX_GAUSS]; };   // 1-D factor of ImageProcessor's Gaussian (by value in the kernel arguments)
+
 // ---- final-kernel tile
 #define LG_TW 64
 #ifndef LG_TH
@@ -72,8 +75,9 @@ struct LgFinalArgs {
     float min_edge_distance, stem_valid_thresh;
     float inv_maxd;
     float inv_2s2, iso_ramp_step;   // 1 / (2 optimal_distance^2) (float32 reciprocal), (ramp_bottom - ramp_top) / (H - 1)
-    float k1[5];  // separable 1-D Gaussian (size 5, sigma 5/6)
-    int no_skip;    // 1: disable the off-mask fast path (LG_NO_SKIP=1, A/B measurements)
+    float k1[7];  // separable 1-D Gaussian: 2 * gauss_r + 1 taps, sigma = size / 6 (image_processor.py:25-32)
+    int gauss_r;    // radius of that Gaussian: 0..3 (lg_params.gaussian_size 1, 3, 5, 7)
+    int no_skip;    // bit 0: tile-level constant path off, bit 1: wave-level off-leaf shortcut off (LG_NO_SKIP; same results, A/B timing)
     int nt_stores;  // 0: plain stores (default); 1: non-temporal plane stores (LG_NT_STORES=1; measured slower)
     int persist;    // 1: resident workgroups walk the tiles (lg_launch_final); 0: one workgroup per tile
     int tpw;        // > 0: consecutive tiles per workgroup (set by lg_launch_final)
@@ -94,6 +98,7 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
 void lg_launch_dout_border(const unsigned long long* bits, const LgWin* win, uint32_t* maxfix, int B, int H, int W, int WW,
                            hipStream_t s);
 void lg_launch_final(const LgFinalArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void lg_launch_smooth(const float* src, float* dst, int B, int H, int W, int S, const LgGaussTaps& taps, hipStream_t s);
 void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth, unsigned long long* tilekeys,
                     bool keys_ready, int B, int H, int W, int k, int min_dist, int32_t* out_xy, int32_t* out_n,
                     float* out_info, hipStream_t s);

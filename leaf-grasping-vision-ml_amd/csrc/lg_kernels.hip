@@ -726,10 +726,14 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
 __device__ __forceinline__ float lg_uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // VEC: W % 4 == 0 (16-byte loads / stores everywhere); ALL: every plane and the validity plane are wanted (the grasp-selection
 // call with the CNN): the instantiation for the usual case carries no per-plane null checks and no scalar store paths.
-template <bool VEC, bool ALL>
+// R: radius of the separable Gaussian of ImageProcessor.smooth_depth (gaussian_size = 2R+1: 1, 3, 5 = the node's, 7); the
+// stencil reaches HALO = R + 1 pixels (Gaussian, then the 3x3 Sobel).
+template <bool VEC, bool ALL, int R>
 __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinalArgs a_) {
+    constexpr int HALO = R + 1;
+    static_assert(R >= 0 && HALO <= 4, "the depth tile carries 4 halo columns");
     constexpr int DW = 72;             // dm tile: cols tx0-4 .. tx0+67
-    constexpr int DH = LG_TH + 6;      // rows ty0-3 .. ty0+34
+    constexpr int DH = LG_TH + 2 * HALO;   // rows ty0-HALO .. ty0+LG_TH-1+HALO
     constexpr int GW = LG_TW + 2;      // g tile: cols tx0-1 .. tx0+64
     constexpr int GH = LG_TH + 2;
     __shared__ __attribute__((aligned(16))) float s_dm[DH * DW];
@@ -796,7 +800,9 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     auto st4 = [&](int mi, unsigned off, int x0, const float* v) {
         float* dst = ap->maps[mi];
         if (!ALL && !dst) return;
-        if ((ap->no_skip & 8) && mi != LG_MAP_TRADITIONAL) return;   // ablation: arithmetic without the plane stores
+#ifdef LG_FINAL_ABLATE   // timing ablation builds only (tools/build_variants.sh): wrong results by design
+        if ((LG_FINAL_ABLATE & 8) && mi != LG_MAP_TRADITIONAL) return;   // arithmetic without the plane stores
+#endif
         char* p = (char*)(dst + fo) + off * 4u;
         if (vec) {
             lg_f4 pk = {v[0], v[1], v[2], v[3]};
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     float zero = 0.0f;
     asm volatile("" : "+v"(zero));   // (a zero the compiler cannot keep in registers across tiles)
     // ---- tile-level fast path.  A leaf covers a few per cent of the frame: when no mask bit lies in this tile's extended
-    //      region (tile + the 3-pixel reach of the 5x5 Gaussian and 3x3 Sobel), depth * mask is 0 all over it, the smoothed
+    //      region (tile + the HALO-pixel reach of the Gaussian and the 3x3 Sobel), depth * mask is 0 all over it, the smoothed
     //      plane and both gradients are 0 and flatness = exp(-5 * 0) = 1 exactly; every other plane is "* mask" = 0,
     //      traditional = w_flat * 1, nothing is valid.  Such tiles never read depth and skip the stencil phases.
     //      Wave 0 looks at the DH x 3 (row, word) pairs and posts the verdict; s_any alternates between two slots so that a
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
             unsigned long long nz = 0;
             for (int e = t; e < DH * 3; e += 64) {
                 const int er = e / 3, wq = e % 3;                 // extended row, word (left neighbour, own, right neighbour)
-                const int y = lg_reflect(ty0 - 3 + er, H), wi = bx - 1 + wq;
+                const int y = lg_reflect(ty0 - HALO + er, H), wi = bx - 1 + wq;
                 if (wi >= 0 && wi < WW) {
                     unsigned long long v = bits_at(bits, y, wi);
                     if (wq == 0) v >>= 56;                        // columns tx0-8 .. tx0-1 (halo 4 + reflection slack)
@@ -901,7 +907,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     if (fast) {
         for (int idx = t; idx < DH * (DW / 4); idx += 256) {
             int er = idx / (DW / 4), g4 = idx % (DW / 4);
-            int y = lg_reflect(ty0 - 3 + er, H);
+            int y = lg_reflect(ty0 - HALO + er, H);
             int x = tx0 - 4 + 4 * g4;
             float4 d = *reinterpret_cast<const float4*>(depth + (unsigned)(y * W + x) * 4u);
             unsigned long long wbits = bits_at(bits, y, x >> 6);
@@ -916,7 +922,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
     } else {
         for (int idx = t; idx < DH * DW; idx += 256) {
             int er = idx / DW, ec = idx % DW;
-            int y = lg_reflect(ty0 - 3 + er, H);
+            int y = lg_reflect(ty0 - HALO + er, H);
             int x = lg_reflect(tx0 - 4 + ec, W);
             float d = *reinterpret_cast<const float*>(depth + (unsigned)(y * W + x) * 4u);
             unsigned long long wbits = bits_at(bits, y, x >> 6);
@@ -924,7 +930,8 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
         }
     }
     lg_lds_barrier();
-    if (ap->no_skip & 16) {   // ablation: the memory traffic of the dense path without its arithmetic
+#ifdef LG_FINAL_ABLATE
+    if (LG_FINAL_ABLATE & 16) {   // ablation build: the memory traffic of the dense path without its arithmetic
 #pragma unroll
         for (int rr = 0; rr < RPT; rr++) {
             const int y = ty0 + tyi + 16 * rr, x0 = tx0 + 4 * txi;
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
                 const unsigned off = (unsigned)(y * W + x0);
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = din_pre[rr][j] + s_dm[(tyi + 16 * rr + 3) * DW + 4 + 4 * txi + j] + (float)mnib_pre[rr] + (float)snib_pre[rr];
+                for (int j = 0; j < 4; j++) v[j] = din_pre[rr][j] + s_dm[(tyi + 16 * rr + HALO) * DW + 4 + 4 * txi + j] + (float)mnib_pre[rr] + (float)snib_pre[rr];
                 st4(LG_MAP_SDF, off, x0, v); st4(LG_MAP_APPROACH, off, x0, v); st4(LG_MAP_FLATNESS, off, x0, v);
                 st4(LG_MAP_ISOLATION, off, x0, v); st4(LG_MAP_ACCESS, off, x0, v); st4(LG_MAP_STEM, off, x0, v);
                 st4(LG_MAP_TRADITIONAL, off, x0, v);
@@ -943,47 +950,56 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
         lg_lds_barrier();
         continue;
     }
-    // ---- separable 5-tap Gaussian; g is stored at the *reflect-padded* coordinates the Sobel stage reads
+#endif
+    // ---- separable (2R+1)-tap Gaussian; g is stored at the *reflect-padded* coordinates the Sobel stage reads
     //      (F.pad(g,(1,1,1,1),'reflect'), grasp_point_selector.py:648): g_ext(e) = G(reflect1(e)).
     // Work split without div/mod: thread t owns column (t & 63) for rows (t >> 6) + 4k; the two extra halo
     // columns (64, 65) are covered by the first threads afterwards.
     {
-        const float k0 = ap->k1[0], k1 = ap->k1[1], k2 = ap->k1[2], k3 = ap->k1[3], k4 = ap->k1[4];
+        float kw[2 * R + 1];
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; i++) kw[i] = ap->k1[i];
+        auto tap_row = [&](const float* p) {   // taps in ascending order, like the 5-tap form this generalises
+            float acc = kw[0] * p[0];
+#pragma unroll
+            for (int i = 1; i < 2 * R + 1; i++) acc += kw[i] * p[i];
+            return acc;
+        };
+        auto tap_col = [&](const float* p) {
+            float acc = kw[0] * p[0];
+#pragma unroll
+            for (int i = 1; i < 2 * R + 1; i++) acc += kw[i] * p[i * GW];
+            return acc;
+        };
         const int ec = t & 63;
         int lc = lg_reflect(tx0 - 1 + ec, W) - (tx0 - 4);
-        lc = lc < 2 ? 2 : (lc > DW - 3 ? DW - 3 : lc);
+        lc = lc < R ? R : (lc > DW - 1 - R ? DW - 1 - R : lc);
 #pragma unroll
         for (int k = 0; k < (DH + 3) / 4; k++) {
             const int er = (t >> 6) + 4 * k;
-            if (er < DH) {
-                const float* p = &s_dm[er * DW + lc - 2];
-                s_h[er * GW + ec] = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4];
-            }
+            if (er < DH) s_h[er * GW + ec] = tap_row(&s_dm[er * DW + lc - R]);
         }
         if (t < 2 * DH) {
             const int er = t >> 1, ec2 = 64 + (t & 1);
             int lc2 = lg_reflect(tx0 - 1 + ec2, W) - (tx0 - 4);
-            lc2 = lc2 < 2 ? 2 : (lc2 > DW - 3 ? DW - 3 : lc2);
-            const float* p = &s_dm[er * DW + lc2 - 2];
-            s_h[er * GW + ec2] = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4];
+            lc2 = lc2 < R ? R : (lc2 > DW - 1 - R ? DW - 1 - R : lc2);
+            s_h[er * GW + ec2] = tap_row(&s_dm[er * DW + lc2 - R]);
         }
         lg_lds_barrier();
 #pragma unroll
         for (int k = 0; k < (GH + 3) / 4; k++) {
             const int gr = (t >> 6) + 4 * k;
             if (gr < GH) {
-                int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
-                lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
-                const float* p = &s_h[(lr - 2) * GW + ec];
-                s_g[gr * (GW + 2) + ec] = k0 * p[0] + k1 * p[GW] + k2 * p[2 * GW] + k3 * p[3 * GW] + k4 * p[4 * GW];
+                int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - HALO);
+                lr = lr < R ? R : (lr > DH - 1 - R ? DH - 1 - R : lr);
+                s_g[gr * (GW + 2) + ec] = tap_col(&s_h[(lr - R) * GW + ec]);
             }
         }
         if (t < 2 * GH) {
             const int gr = t >> 1, ec2 = 64 + (t & 1);
-            int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - 3);
-            lr = lr < 2 ? 2 : (lr > DH - 3 ? DH - 3 : lr);
-            const float* p = &s_h[(lr - 2) * GW + ec2];
-            s_g[gr * (GW + 2) + ec2] = k0 * p[0] + k1 * p[GW] + k2 * p[2 * GW] + k3 * p[3 * GW] + k4 * p[4 * GW];
+            int lr = lg_reflect(ty0 - 1 + gr, H) - (ty0 - HALO);
+            lr = lr < R ? R : (lr > DH - 1 - R ? DH - 1 - R : lr);
+            s_g[gr * (GW + 2) + ec2] = tap_col(&s_h[(lr - R) * GW + ec2]);
         }
     }
     lg_lds_barrier();
@@ -1152,12 +1168,68 @@ void lg_launch_final(const LgFinalArgs& a_in, hipStream_t s, hipEvent_t ev_start
     bool all = a.valid != nullptr;
     for (int i = 0; i < LG_NUM_MAPS; i++) all = all && a.maps[i] != nullptr;
     const bool vec = (a.W & 3) == 0;
-    auto k = vec ? (all ? lg_final_kernel<true, true> : lg_final_kernel<true, false>)
-                 : (all ? lg_final_kernel<false, true> : lg_final_kernel<false, false>);
+    void (*k)(LgFinalArgs) = nullptr;
+#define LG_FINAL_PICK(RR)                                                                                  \
+    k = vec ? (all ? lg_final_kernel<true, true, RR> : lg_final_kernel<true, false, RR>)                   \
+            : (all ? lg_final_kernel<false, true, RR> : lg_final_kernel<false, false, RR>)
+    switch (a.gauss_r) {   // make_plan admits gaussian_size 1, 3, 5, 7 only
+        case 0: LG_FINAL_PICK(0); break;
+        case 1: LG_FINAL_PICK(1); break;
+        case 3: LG_FINAL_PICK(3); break;
+        default: LG_FINAL_PICK(2); break;
+    }
+#undef LG_FINAL_PICK
     if (ev_start && ev_stop)  // events stamped by the command processor right around this dispatch
         hipExtLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, a);
     else
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, a);
+}
+
+// ============================================================================ ImageProcessor.smooth_depth on its own
+// image_processor.py:56-64: F.pad(depth, size // 2 on every side, 'reflect') then F.conv2d with the size x size Gaussian (a
+// cross-correlation; the kernel is symmetric).  Output (H + 2P - S + 1) x (W + 2P - S + 1), P = S / 2: the input's shape for odd
+// S, one row and one column more for even S (what torch returns there).  Separable: rows, then columns, taps in ascending
+// order -- the same two passes as the stencil phase of lg_final_kernel.  Tile 64 x 16 outputs, 256 threads, any 1 <= S <= 15.
+__global__ __launch_bounds__(256) void lg_smooth_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                        int Ho, int Wo, int S, LgGaussTaps taps) {
+    constexpr int TW = 64, TH = 16, MAXS = LG_MAX_GAUSS;
+    __shared__ float s_in[(TH + MAXS - 1) * (TW + MAXS - 1)];
+    __shared__ float s_row[(TH + MAXS - 1) * TW];
+    const int t = threadIdx.x, P = S >> 1;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const float* in = src + (size_t)blockIdx.z * H * W;
+    float* out = dst + (size_t)blockIdx.z * Ho * Wo;
+    const int IW = TW + S - 1, IH = TH + S - 1;
+    for (int i = t; i < IH * IW; i += 256) {
+        const int er = i / IW, ec = i - er * IW;
+        // output (y, x) reads padded[y + i][x + j] = in[reflect(y + i - P)][reflect(x + j - P)]; rows / columns past the output
+        // (partial tiles) are clamped by lg_reflect and never stored
+        s_in[i] = in[(size_t)lg_reflect(ty0 + er - P, H) * W + lg_reflect(tx0 + ec - P, W)];
+    }
+    __syncthreads();
+    for (int i = t; i < IH * TW; i += 256) {
+        const int er = i >> 6, c = i & 63;
+        const float* p = &s_in[er * IW + c];
+        float acc = taps.k[0] * p[0];
+        for (int j = 1; j < S; j++) acc += taps.k[j] * p[j];
+        s_row[i] = acc;
+    }
+    __syncthreads();
+    for (int i = t; i < TH * TW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int y = ty0 + r, x = tx0 + c;
+        if (y < Ho && x < Wo) {
+            const float* p = &s_row[r * TW + c];
+            float acc = taps.k[0] * p[0];
+            for (int j = 1; j < S; j++) acc += taps.k[j] * p[j * TW];
+            out[(size_t)y * Wo + x] = acc;
+        }
+    }
+}
+
+void lg_launch_smooth(const float* src, float* dst, int B, int H, int W, int S, const LgGaussTaps& taps, hipStream_t s) {
+    const int P = S / 2, Ho = H + 2 * P - S + 1, Wo = W + 2 * P - S + 1;
+    hipLaunchKernelGGL(lg_smooth_kernel, dim3((Wo + 63) / 64, (Ho + 15) / 16, B), dim3(256), 0, s, src, dst, H, W, Ho, Wo, S, taps);
 }
 
 __global__ __launch_bounds__(256) void lg_tilekeys_kernel(const float* __restrict__ trad,

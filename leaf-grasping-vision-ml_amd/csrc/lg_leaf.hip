@@ -873,7 +873,7 @@ struct LgLeafWs {   // every array holds capB frames back to back
     lg_leaf_stat* h_out;       // ... and their pinned host copies
     LeafHdr* h_hdr;
     int out_cap;
-    size_t px_cap, g_cap, rb_cap;
+    size_t px_cap, bits_cap, g_cap, rb_cap;   // pixels (comp list), 64-bit words of the bit rows, pixels, rows
     int capB;
     hipEvent_t ev_in, ev_side; // fences of the side chain (the side stream belongs to the handle)
 };
@@ -911,16 +911,22 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
             return LG_ERR_HIP;
         w->capB = B;
     }
-    const size_t need = (size_t)w->capB * H * W;
-    if (need > w->px_cap) {
+    // the bit rows are H rows of ceil(W / 64) words: their word count does not follow the pixel count (480 x 640 needs 4800
+    // words per frame, 640 x 480 needs 5120), so it has a capacity of its own
+    const size_t need = (size_t)w->capB * H * W, need_words = (size_t)w->capB * H * ((W + 63) / 64);
+    if (need_words > w->bits_cap) {
         if (w->bits) hipFree(w->bits);
+        w->bits = nullptr;
+        w->bits_cap = 0;
+        if (hipMalloc((void**)&w->bits, need_words * 8)) return LG_ERR_NOMEM;
+        w->bits_cap = need_words;
+    }
+    if (need > w->px_cap) {
         if (w->comp) hipFree(w->comp);
-        w->bits = w->comp = nullptr;
+        w->comp = nullptr;
         w->px_cap = 0;
-        // (bits: H rows of ceil(W/64) words <= H * W / 8 + H * 8 bytes)
         // (comp: per frame the segments of up to 256 workgroups, each rounded up to whole 4096-pixel steps)
-        if (hipMalloc((void**)&w->bits, (size_t)w->capB * H * ((W + 63) / 64) * 8) ||
-            hipMalloc((void**)&w->comp, (need + (size_t)w->capB * 256 * 4096 * 2) * 8)) return LG_ERR_NOMEM;
+        if (hipMalloc((void**)&w->comp, (need + (size_t)w->capB * 256 * 4096 * 2) * 8)) return LG_ERR_NOMEM;
         w->px_cap = need;
     }
     return LG_OK;

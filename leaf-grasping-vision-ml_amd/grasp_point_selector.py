@@ -17,6 +17,7 @@ from . import _lib
 from ._lib import LG_NUM_MAPS, MAP_NAMES, LgGraspResult, check, lib
 from ._log import logerr, loginfo, logwarn
 from .cnn import pack_state_dict
+from .image_processor import flatness_config
 
 # LgGraspResult rows as a numpy record (select_grasp_points_batch reads whole columns)
 _RESULT_DTYPE = np.dtype([(n, np.int32 if t is C.c_int else np.float32) for n, t in LgGraspResult._fields_])
@@ -101,13 +102,17 @@ class GraspPointSelector:
         self.camera_cy = projection_matrix[1, 2]
         self.baseline = -projection_matrix[0, 3] / self.f_norm
 
-    def _sync_params(self):
+    def _sync_params(self, image_processor=None):
         if self.f_norm is None:
             # reference: np.full(..., None) in calculate_approach_vector_score raises -> caught -> None triple
             raise RuntimeError("camera parameters not set (f_norm is None): call set_camera_params first")
         p = self.params
         p.cx, p.cy, p.f = float(self.camera_cx), float(self.camera_cy), float(self.f_norm)
         p.min_edge_distance = float(self.min_edge_distance)
+        # _calculate_flatness_map smooths with the CALLER's ImageProcessor (:635-657 -> image_processor.py:56-64): its
+        # Gaussian size goes into lg_params (1 / 3 / 5 / 7; anything else is refused by the library, an even size fails in
+        # the reference as well).  None (not possible in the reference) = the node's size 5.
+        p.gaussian_size = 5 if image_processor is None else flatness_config(image_processor)
         return p
 
     # ------------------------------------------------------------------ tensors
@@ -141,12 +146,12 @@ class GraspPointSelector:
         return maps, ptrs
 
     # ------------------------------------------------------------------ score planes (:256-288)
-    def score_maps(self, leaf_mask, depth_tensor):
+    def score_maps(self, leaf_mask, depth_tensor, image_processor=None):
         """All eight planes + validity mask, device resident.
         Returns (dict name -> float32 tensor [B,H,W] or [H,W], valid uint8 tensor, theta list)."""
         m, d, _ = self._prep_inputs(leaf_mask, depth_tensor)
         B, H, W = m.shape
-        p = self._sync_params()
+        p = self._sync_params(image_processor)
         maps, ptrs = self._alloc_maps(B, H, W)
         valid = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
         theta = (C.c_float * B)()
@@ -171,7 +176,7 @@ class GraspPointSelector:
 
     def _calculate_all_scores(self, leaf_mask_np, depth_tensor, image_processor=None):
         """Reference signature (:256): numpy uint8 mask in, dict of numpy planes out."""
-        out, _, _ = self.score_maps(leaf_mask_np, depth_tensor)
+        out, _, _ = self.score_maps(leaf_mask_np, depth_tensor, image_processor)
         return {k: v.cpu().numpy() for k, v in out.items()}
 
     def _get_valid_regions(self, leaf_mask_np, scores):  # :282-288 (host helper for callers holding a scores dict)
@@ -254,11 +259,11 @@ class GraspPointSelector:
             return None
 
     # ------------------------------------------------------------------ the path (:184-253)
-    def select_grasp_points_batch(self, leaf_masks, depth_tensors, return_maps=False):
+    def select_grasp_points_batch(self, leaf_masks, depth_tensors, return_maps=False, image_processor=None):
         """B frames at once ([B,H,W] mask + depth).  Returns a list of (xy, XYZ, preXYZ) triples."""
         m, d, is_bool = self._prep_inputs(leaf_masks, depth_tensors)
         B, H, W = m.shape
-        p = self._sync_params()
+        p = self._sync_params(image_processor)
         p.mask_is_bool = 1 if is_bool else 0
         maps = valid = None
         ptrs = None
@@ -286,7 +291,7 @@ class GraspPointSelector:
     def select_grasp_point(self, leaf_mask, depth_tensor, image_processor=None, pcl_data=None):
         """Select optimal grasp point using combined traditional and ML approach (reference :184)."""
         try:
-            res = self.select_grasp_points_batch(leaf_mask, depth_tensor)[0]
+            res = self.select_grasp_points_batch(leaf_mask, depth_tensor, image_processor=image_processor)[0]
             if res[0] is None:
                 logwarn("No valid candidate points found")
             return res

@@ -1,10 +1,67 @@
 """ImageProcessor -- mirror of scripts/utils/image_processor.py (same constructor, attributes and methods).
-The kernels it hands out (`get_kernel`) are kept for API compatibility; the flatness stencil itself runs
-inside the fused HIP score-map kernel (Gaussian 5x5 sigma=size/6 o Sobel 3x3, reflect padding)."""
+
+`smooth_depth` runs in liblgrasp.so (`lg_smooth_depth`: reflect padding + the separable form of the object's own
+Gaussian); the flatness stencil of the scoring path runs inside the fused HIP plane kernel with the Gaussian size of
+the ImageProcessor the caller hands to `select_grasp_point` (`flatness_config`).  There is no CPU / torch fallback.
+The kernels `get_kernel` hands out are the reference's tensors (API compatibility; the library multiplies with the
+1-D factor of the same Gaussian, `lg_gaussian_taps`)."""
 import colorsys
+import ctypes as C
 
 import numpy as np
 import torch
+
+from ._lib import check, lib
+
+_SOBEL_X = ((-1.0, 0.0, 1.0), (-2.0, 0.0, 2.0), (-1.0, 0.0, 1.0))
+_handles = {}   # device index -> lg_handle for the stateless lg_smooth_depth calls (created once per device, never destroyed)
+
+
+def _handle(index):
+    h = _handles.get(index)
+    if h is None:
+        h = C.c_void_p()
+        check(None, lib.lg_create(index, C.byref(h)), "lg_create")
+        _handles[index] = h
+    return h
+
+
+def gaussian_taps(size):
+    """The 1-D factor the library multiplies with (outer(t, t) == _create_gaussian_kernel(size) up to rounding)."""
+    out = (C.c_float * int(size))()
+    if lib.lg_gaussian_taps(int(size), out) != 0:
+        raise ValueError(f"gaussian size {size} is outside [1, 15]")
+    return np.array(out, np.float32)
+
+
+def _kernel(image_processor, name):
+    k = image_processor.get_kernel(name, "cpu")
+    if k is None:
+        raise ValueError(f"image_processor has no '{name}' kernel")
+    return np.asarray(torch.as_tensor(k).detach().cpu(), np.float64)
+
+
+def gaussian_config(image_processor):
+    """Size of the object's smoothing kernel, after checking that it IS `_create_gaussian_kernel(size)` -- the library
+    applies that Gaussian (as its two 1-D factors) and nothing else: a different kernel is refused, not replaced."""
+    g = _kernel(image_processor, "gaussian")
+    if g.ndim != 2 or g.shape[0] != g.shape[1]:
+        raise ValueError(f"gaussian kernel of shape {g.shape} is not square")
+    size = int(g.shape[0])
+    t = gaussian_taps(size).astype(np.float64)
+    if not np.allclose(g, np.outer(t, t), rtol=1e-5, atol=1e-9):
+        raise ValueError("image_processor carries a smoothing kernel other than _create_gaussian_kernel(size): unsupported")
+    return size
+
+
+def flatness_config(image_processor):
+    """Gaussian size of the smoothing `_calculate_flatness_map` (grasp_point_selector.py:635-657) applies with this
+    ImageProcessor; the gradient kernels it reads from the same object must be the reference's Sobel pair."""
+    size = gaussian_config(image_processor)
+    sx, sy = _kernel(image_processor, "sobel_x"), _kernel(image_processor, "sobel_y")
+    if sx.shape != (3, 3) or not np.array_equal(sx, np.array(_SOBEL_X)) or not np.array_equal(sy, np.array(_SOBEL_X).T):
+        raise ValueError("image_processor carries gradient kernels other than the 3x3 Sobel pair: unsupported")
+    return size
 
 
 class ImageProcessor:
@@ -48,10 +105,22 @@ class ImageProcessor:
         y_indices, x_indices = torch.where(leaf_mask)
         return (float(x_indices.float().mean()), float(y_indices.float().mean()))
 
-    def smooth_depth(self, depth_patch, device):  # :56-64 (kept for callers; not on the hot path any more)
-        import torch.nn.functional as F
-
-        g = self.get_kernel("gaussian", device)
-        d = depth_patch.to(device)
-        padded = F.pad(d.unsqueeze(0).unsqueeze(0), (g.shape[0] // 2,) * 4, mode="reflect")
-        return F.conv2d(padded, g.view(1, 1, *g.shape), padding=0).squeeze()
+    def smooth_depth(self, depth_patch, device):  # :56-64
+        """Reflect padding by size // 2, then the size x size Gaussian: [H, W] -> [H, W] for odd sizes and, as F.conv2d
+        gives there, [H + 1, W + 1] for even ones.  Runs in liblgrasp.so on `device` (a HIP device)."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"ImageProcessor.smooth_depth needs a HIP device (got '{dev}'): there is no CPU fallback")
+        size = gaussian_config(self)
+        d = torch.as_tensor(depth_patch).to(dev, torch.float32).contiguous()
+        if d.dim() != 2:
+            raise ValueError(f"depth_patch must be [H, W], got {tuple(d.shape)}")
+        H, W = d.shape
+        p = size // 2
+        out = torch.empty((H + 2 * p - size + 1, W + 2 * p - size + 1), dtype=torch.float32, device=dev)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(dev):
+            h = _handle(index)
+            check(h, lib.lg_smooth_depth(h, d.data_ptr(), 1, H, W, size, out.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lg_smooth_depth")
+        return out.squeeze()

@@ -136,7 +136,7 @@ class LeafGraspHarness:
         else:
             sel = torch.tensor(keep, device=self.device)
             optimal, dep = mask_t.index_select(0, sel) == idt, depth_t.index_select(0, sel)
-        res = self.grasp_selector.select_grasp_points_batch(optimal, dep)
+        res = self.grasp_selector.select_grasp_points_batch(optimal, dep, image_processor=self.image_processor)
         for b, (p2, p3, pre) in zip(keep, res):
             if p2 is not None:
                 out[offset + b] = self.format_result(p2, p3, pre)

@@ -73,7 +73,7 @@ Respond with only a decimal number between 0.0 and 1.0.
         try:
             inputs = self.processor(prompt, image, return_tensors="pt").to(self.device)
             with torch.no_grad():
-                output = self.model.generate(**inputs, max_new_tokens=10, do_sample=False)
+                output = self.model.generate(**inputs, max_new_tokens=10, do_sample=False, temperature=0.1)  # :85-90
             response = self.processor.decode(output[0], skip_special_tokens=True).split("assistant")[-1].strip()
             try:
                 return float(np.clip(float(response), 0.0, 1.0))

@@ -1,6 +1,7 @@
 """GPU parity of the leaf-selection stage (OptimalLeafSelector), the ROS-free node harness and the
 HybridGraspSelector facade against the CPU oracle."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -62,9 +63,11 @@ def test_leaf_statistics_and_selection(L, shape, seed):
 # field is the EXACT Euclidean distance, the reference's is skfmm's second-order fast-marching approximation
 # (leaf_scorer.py:66-71), restated in oracle/lg_oracle.c::lg_fmm_distance.  Over 120 scenes (40 seeds x 720p / native /
 # 1080p, /tmp sweep of round 2): arg-max moved by <= 1 px, |d clutter_score| <= 2.7e-4, 0 different leaf ids, 0 different
-# tall-leaf lists.  The bounds asserted here leave a 2-4x margin over that.
-_FMM_ARGMAX_PX = 2.0
-_FMM_CLUTTER_ABS = 1e-3
+# tall-leaf lists; on the HIP path in these 36 scenes: 1 px, 2.8e-4 absolute on scores of 0.3-0.7, i.e. up to ~5e-4 RELATIVE --
+# above north_star's 1e-4 float bar: this is the documented deviation of the substitution, not rounding.  The bounds asserted
+# are the measured values plus a margin (1 px is the grid; 4e-4 = 1.4 x measured).
+_FMM_ARGMAX_PX = 1.0
+_FMM_CLUTTER_ABS = 4e-4
 
 
 @pytest.mark.parametrize("shape", [(720, 1280), (1080, 1440), (1080, 1920)])
@@ -422,6 +425,73 @@ def test_hybrid_grasp_selector_facade(L):
     hg2.select_grasp_point(None, cands, torch.from_numpy(depth).cuda())
     assert hg2.last_selection["leaf_id"] == cands[0]["leaf_id"]
     assert hg2.select_grasp_point(None, [], None) == (None, None, None)
+
+
+def test_hybrid_grasp_selector_with_the_llava_scorer_on_a_scripted_model(L):
+    """BASELINE config 5's composition (leaf_grasp_node_vla.py:97-139,184-190) end to end on the HIP path with the real
+    LLaVAScorer class driving a scripted (processor, model) pair -- the weights do not exist on this filesystem: candidates
+    -> prompts -> generate / decode / parse -> normalise -> ConfidenceManager -> HybridSelector -> select_grasp_point on
+    the winner's mask, against the same composition of the reference-pinned host classes and the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from leafgrasp_amd.vla_scorer import LLaVAScorer
+    from scripted_llava import ScriptedModel, ScriptedProcessor
+    H, W = 720, 1280
+    labels, depth, P = O.synthetic_scene(H, W, 2)
+    scorer = LLaVAScorer(device="cuda:0", model_path=None)
+    hg = L.HybridGraspSelector("cuda:0", vla_scorer=scorer, load_model=False)
+    hg.set_camera_params(P)
+    dt = torch.from_numpy(depth).cuda()
+    cands = hg.generate_candidates(torch.from_numpy(labels).cuda(), dt)
+    assert len(cands) >= 3
+    geo = [c["geometric_score"] for c in cands]
+    img = np.zeros((H, W, 3), np.uint8)
+    rg = O.RefGraspPointSelector()
+    rg.set_camera_params(P)
+    # scripts: the model prefers the geometrically WORST candidate strongly / answers garbage / fails on one candidate
+    n = len(cands)
+    scripts = [["assistant\n%.2f" % (0.05 + 0.9 * i / (n - 1)) for i in range(n)],
+               ["assistant I cannot rate this"] * n,
+               ["assistant 0.9", "!raise"] + ["assistant 0.2"] * (n - 2)]
+    winners = []
+    for script in scripts:
+        scorer.processor, scorer.model = ScriptedProcessor(script), ScriptedModel(script)
+        hg.confidence_manager = L.ConfidenceManager()
+        res = hg.select_grasp_point(img, cands, dt)
+        assert len(scorer.processor.prompts) == n and "Geometric score: %.3f" % geo[0] in scorer.processor.prompts[0]
+        raw = []
+        for t in script:   # llava_processor.py:92-101 applied by hand
+            try:
+                raw.append(0.5 if t == "!raise" else float(np.clip(float(t.split("assistant")[-1].strip()), 0.0, 1.0)))
+            except ValueError:
+                raw.append(0.5)
+        raw = np.array(raw)
+        vla = [0.5] * n if raw.std() < 1e-6 else ((raw - raw.min()) / (raw.max() - raw.min())).tolist()
+        conf = L.ConfidenceManager().calculate_confidence(vla, geo)
+        exp_win = L.HybridSelector("cpu").select_best_candidate(cands, geo, vla, conf)
+        assert hg.last_selection["leaf_id"] == exp_win["leaf_id"]
+        assert hg.last_selection["hybrid_score"] == pytest.approx(exp_win["hybrid_score"], rel=1e-12)
+        winners.append(exp_win["leaf_id"])
+        exp = rg.select_grasp_point((labels == exp_win["leaf_id"]).astype(np.uint8), depth)
+        assert res[0] == exp[0]
+        np.testing.assert_allclose(res[1], exp[1], rtol=1e-5)
+        np.testing.assert_allclose(res[2], exp[2], rtol=1e-5)
+    assert winners[0] != cands[0]["leaf_id"], "a confident scorer must be able to overrule the geometric arg-max"
+    assert winners[1] == cands[0]["leaf_id"]          # constant 0.5 scores -> the geometric ranking decides
+
+
+def test_leaf_workspace_survives_a_change_of_aspect(L):
+    """the leaf stage's bit rows are H x ceil(W / 64) words -- 480 x 640 needs 4800 per frame, 640 x 480 needs
+    5120 at the same pixel count.  One handle, both shapes, either order: statistics and selection equal the oracle."""
+    sel = L.OptimalLeafSelector(torch.device("cuda:0"))
+    for shape in ((480, 640), (640, 480), (600, 450), (480, 640), (300, 1000), (1000, 300)):
+        labels, depth, P = O.synthetic_scene(*shape, 7)
+        sel.set_camera_params(P)
+        ref = O.RefOptimalLeafSelector(field="edt")
+        ref.set_camera_params(P)
+        assert sel.select_optimal_leaf(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda()) == \
+            ref.select_optimal_leaf(labels, depth), shape
+        assert sel.get_tall_leaves() == ref.get_tall_leaves()
 
 
 def test_leaf_selection_batch_equals_per_frame(L):

@@ -302,6 +302,47 @@ def test_cnn_winograd_matches_direct(sel, monkeypatch):
     sel.clear_cnn()
 
 
+def _wide_range_params(seed):
+    """The closed-form fill with a WIDE dynamic range in the BatchNorm terms that fold into the conv weights: gamma
+    log-uniform in [0.25, 4], running_var log-uniform in [1e-2, 1] (per-channel scale gamma / sqrt(var + eps) from 0.25 to
+    40; trained checkpoints sit inside that), running_mean up to +-0.5.  The benign fill of synthetic_inputs.py has
+    gamma in [0.9, 1.1] and var in [0.8, 1.2]."""
+    params = O.cnn_closed_form_params(seed=seed)
+    rng = np.random.default_rng(1000 + seed)
+    for k in list(params):
+        if k.startswith("encoder") and k.endswith("running_var"):
+            params[k] = np.exp(rng.uniform(np.log(1e-2), 0.0, params[k].shape)).astype(np.float32)
+        elif k.startswith("encoder") and k.endswith("running_mean"):
+            params[k] = rng.uniform(-0.5, 0.5, params[k].shape).astype(np.float32)
+        elif k.startswith("encoder") and k.endswith(".weight") and params[k].ndim == 1:
+            params[k] = np.exp(rng.uniform(np.log(0.25), np.log(4.0), params[k].shape)).astype(np.float32)
+    return params
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cnn_forms_hold_1e4_on_wide_dynamic_range_weights(sel, monkeypatch, seed):
+    """Winograd F(4x4,3x3) loses digits with the dynamic range of the BN-folded weights.  All three forms
+    of the conv layers -- F(4x4,3x3) (default), F(2x2,3x3), direct -- against the float64 oracle at the 1e-4 bar on a fill
+    whose folded per-channel scales span 0.25 ... 40."""
+    import torch as T
+    params = _wide_range_params(seed)
+    x = O.synthetic_patches(24, seed=11 + seed)
+    ref = O.cnn_forward(params, x, dtype=T.float64)
+    scale = np.abs(ref).max()
+    errs = {}
+    for name, env in (("direct", {"LG_CNN_DIRECT": "1"}), ("f23", {"LG_CNN_F23": "1"}), ("f43", {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sel.set_cnn_state_dict(params)
+        for k in env:
+            monkeypatch.delenv(k)
+        got = sel.cnn_forward(T.from_numpy(x).cuda()).cpu().numpy()
+        errs[name] = float(np.abs(got - ref).max() / scale)
+    print("wide-range CNN: max |err| / max |logit| =", errs, "max |logit|", scale)
+    sel.clear_cnn()
+    assert all(e <= 1e-4 for e in errs.values()), errs
+
+
 def test_cnn_attention_variants_vs_reference(sel):
     """The sweep's attention variants (model.py:30-60) through lg_cnn_load / lg_cnn_forward vs the reference's outputs."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_variant_vectors.npz"))
@@ -443,6 +484,153 @@ def test_4k_all_planes_vs_oracle(sel):
     """BASELINE config 4 (2160x3840): all eight planes + valid against the oracle (float planes 1e-4, integer work exact)."""
     labels, depth, P = O.synthetic_scene(2160, 3840, 8)
     _compare_maps(sel, (labels == _largest_leaf(labels)).astype(np.uint8), depth, P)
+
+
+# ----------------------------------------------------------------------------- the caller's ImageProcessor is honoured
+@pytest.fixture(scope="module")
+def golden3():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors_r3.npz"))
+
+
+def test_smooth_depth_through_the_library(L, golden, golden3):
+    """ImageProcessor.smooth_depth (image_processor.py:56-64) = lg_smooth_depth, against the REFERENCE's own outputs for
+    Gaussian sizes 1, 3, 5 (the node's), 7 and the even size 4 ((H+1) x (W+1), as F.conv2d returns)."""
+    dm = torch.from_numpy(golden["depth"] * golden["mask"].astype(np.float32)).cuda()
+    for size, ref in ((5, golden["smooth"]), (1, golden3["smooth_1"]), (3, golden3["smooth_3"]), (7, golden3["smooth_7"]),
+                      (4, golden3["smooth_4"])):
+        got = L.ImageProcessor(96, 128, 21, size).smooth_depth(dm, torch.device("cuda:0"))
+        assert got.is_cuda and tuple(got.shape) == ref.shape
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-6, atol=1e-7, err_msg=f"size {size}")
+    # larger sizes and ragged shapes against the oracle's restated smooth_depth (itself pinned by the vectors above)
+    rng = np.random.default_rng(5)
+    for (H, W), size in (((37, 131), 9), ((64, 64), 15), ((17, 300), 11), ((200, 70), 13)):
+        d = rng.random((H, W)).astype(np.float32)
+        got = L.ImageProcessor(H, W, 21, size).smooth_depth(torch.from_numpy(d), "cuda:0").cpu().numpy()
+        np.testing.assert_allclose(got, O.smooth_depth(d, size), rtol=2e-6, atol=1e-7)
+    with pytest.raises(L.LgError):   # torch: reflect padding must be smaller than the input
+        L.ImageProcessor(8, 8, 21, 15).smooth_depth(torch.zeros(7, 7), "cuda:0")
+
+
+def test_flatness_follows_the_callers_image_processor(L, sel, golden, golden3):
+    """_calculate_flatness_map smooths with the ImageProcessor handed to select_grasp_point (grasp_point_selector.py:
+    635-657): sizes 1 / 3 / 7 against the reference's own planes, the whole call against the oracle built with the same
+    size; an even size (shape mismatch in the reference's fusion), a size beyond the kernel's halo and a foreign kernel
+    end in the logged None triple instead of silently scoring with size 5."""
+    H, W = golden["mask"].shape
+    sel.set_camera_params(golden["P"])
+    m, d = torch.from_numpy(golden["mask"]).cuda(), torch.from_numpy(golden["depth"]).cuda()
+    planes = {}
+    for size, ref in ((1, golden3["flatness_1"]), (3, golden3["flatness_3"]), (5, golden["flatness"]), (7, golden3["flatness_7"])):
+        maps, _, _ = sel.score_maps(m, d, L.ImageProcessor(H, W, 21, size))
+        planes[size] = maps["flatness_map"].cpu().numpy()
+        np.testing.assert_allclose(planes[size], ref, rtol=RTOL, atol=ATOL, err_msg=f"gaussian size {size}")
+        sc = sel._calculate_all_scores(golden["mask"], d, L.ImageProcessor(H, W, 21, size))   # the reference's signature
+        np.testing.assert_array_equal(sc["flatness_map"], planes[size])
+    assert np.abs(planes[3] - planes[7]).max() > 1e-2          # (the sizes do differ: honouring them is observable)
+    for seed, size, shape in ((3, 7, (270, 360)), (1, 3, (192, 256)), (5, 7, (720, 1280)), (2, 1, (135, 180))):
+        labels, depth, P = O.synthetic_scene(*shape, seed)
+        mask = (labels == _largest_leaf(labels)).astype(np.uint8)
+        sel.set_camera_params(P)
+        ref = O.RefGraspPointSelector(gaussian_size=size)
+        ref.set_camera_params(P)
+        exp, dbg = ref.select_grasp_point(mask, depth, return_debug=True)
+        ip = L.ImageProcessor(shape[0], shape[1], 21, size)
+        got = sel.select_grasp_point(torch.from_numpy(mask.astype(bool)).cuda(), torch.from_numpy(depth).cuda(), ip)
+        assert got[0] == exp[0], (seed, size)
+        np.testing.assert_allclose(got[1], exp[1], rtol=1e-5)
+        np.testing.assert_allclose(got[2], exp[2], rtol=1e-5)
+        maps, valid, _ = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda(), ip)
+        for k, v in dbg["scores"].items():
+            np.testing.assert_allclose(maps[k].cpu().numpy(), v, rtol=RTOL, atol=ATOL, err_msg=f"{k} size {size}")
+        assert sel._get_candidate_points(maps["traditional_score"], valid, 20, 10) == dbg["candidates"]
+    mb = torch.from_numpy(mask.astype(bool)).cuda()
+    dd = torch.from_numpy(depth).cuda()
+    for bad in (L.ImageProcessor(135, 180, 21, 4), L.ImageProcessor(135, 180, 21, 9)):
+        assert sel.select_grasp_point(mb, dd, bad) == (None, None, None)
+    foreign = L.ImageProcessor(135, 180, 21, 5)
+    foreign.kernels["gaussian"] = torch.ones(5, 5) / 25.0
+    assert sel.select_grasp_point(mb, dd, foreign) == (None, None, None)
+    assert sel.select_grasp_point(mb, dd, L.ImageProcessor(135, 180, 21, 5))[0] is not None
+
+
+# ----------------------------------------------------------------------------- threads (SURVEY 8b "Threading")
+def test_two_handles_on_two_threads_equal_the_serial_results(L):
+    """rospy runs every subscriber callback on its own thread (leaf_grasp_node_v3.py:104-107,185-205): two selector
+    instances driven concurrently from two threads -- 1080p, CNN on, several calls each -- return exactly what the same
+    calls return one after the other."""
+    import threading
+    H, W = 1080, 1920
+    scenes = [O.synthetic_scene(H, W, 100 + s) for s in range(4)]
+    P = scenes[0][2]
+    params = O.cnn_closed_form_params(seed=0)
+    sels = []
+    for _ in range(2):
+        s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+        s.set_camera_params(P)
+        s.set_cnn_state_dict(params)
+        sels.append(s)
+    work = []   # per thread: a list of (masks, depths) batches of different sizes
+    for t in range(2):
+        items = []
+        for rep in range(6):
+            idx = [(t + rep + j) % 4 for j in range(1 + (rep + t) % 3)]
+            items.append((torch.from_numpy(np.stack([scenes[i][0] == _largest_leaf(scenes[i][0]) for i in idx])).cuda(),
+                          torch.from_numpy(np.stack([scenes[i][1] for i in idx])).cuda()))
+        work.append(items)
+    serial = [[sels[t].select_grasp_points_batch(m, d) for m, d in work[t]] for t in range(2)]
+    assert all(r[0] is not None for batch in serial[0] + serial[1] for r in batch)
+    results, errors = [None, None], []
+    start = threading.Barrier(2)
+
+    def run(t):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                start.wait()
+                results[t] = [sels[t].select_grasp_points_batch(m, d) for m, d in work[t]]
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert results == serial
+
+
+def test_second_thread_on_a_busy_handle_is_refused(L):
+    """One call in flight per handle: while a thread is inside lg_select_grasp, another thread entering the SAME handle
+    gets LG_ERR_BUSY (and the running call's results are untouched)."""
+    import ctypes as C
+    import threading
+    from leafgrasp_amd import _lib
+    H, W, B = 1080, 1920, 48
+    labels, depth, P = O.synthetic_scene(H, W, 101)
+    s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    s.set_camera_params(P)
+    s.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
+    m = torch.from_numpy(np.repeat((labels == _largest_leaf(labels))[None], B, 0)).cuda()
+    d = torch.from_numpy(np.repeat(depth[None], B, 0)).cuda()
+    exp = s.select_grasp_points_batch(m, d)
+    torch.cuda.synchronize()
+    got, seen = [], []
+    inside = threading.Event()
+
+    def run():
+        inside.set()
+        for _ in range(4):
+            got.append(s.select_grasp_points_batch(m, d))
+    th = threading.Thread(target=run)
+    th.start()
+    inside.wait()
+    n, ms = C.c_int(0), C.c_double(0)
+    while th.is_alive():
+        seen.append(_lib.lib.lg_profile_read(s._h, b"final", C.byref(n), C.byref(ms)))
+    th.join()
+    assert _lib.LG_ERR_BUSY in seen, "the poller never met the running call"
+    assert set(seen) <= {_lib.LG_OK, _lib.LG_ERR_BUSY}
+    assert got == [exp] * 4
 
 
 def test_error_convention(L):

@@ -10,10 +10,10 @@ import numpy as np
 import pytest
 import torch
 
-import leafgrasp_amd as L
-from leafgrasp_amd import _lib
-
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import leafgrasp_amd as L  # noqa: E402
+from leafgrasp_amd import _lib  # noqa: E402
 
 
 def test_library_exports_every_declared_symbol():
@@ -34,12 +34,12 @@ def test_default_params_are_the_reference_constants():
     assert [round(v, 6) for v in (p.w_approach, p.w_sdf, p.w_flat, p.w_access)] == [0.4, 0.3, 0.2, 0.1]  # :272-277
     assert [round(v, 6) for v in (p.sdf_w_interior, p.sdf_w_align, p.sdf_w_sdf)] == [0.4, 0.4, 0.2]       # :563-565
     assert p.optimal_distance == 20 and p.min_edge_distance == 20 and round(p.stem_valid_thresh, 6) == 0.8
-    assert (p.stem_se, p.stem_bottom_div, p.top_k, p.nms_min_distance, p.pregrasp_clearance) == (30, 3, 20, 10, 15)
+    assert (p.stem_se, p.stem_bottom_div, p.top_k, p.nms_min_distance, p.pregrasp_clearance, p.gaussian_size) == (30, 3, 20, 10, 15, 5)
 
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    assert C.sizeof(_lib.LgParams) == 3 * 8 + 23 * 4 + 4  # 3 doubles, 17 floats, 6 int32, tail padding to 8
+    assert C.sizeof(_lib.LgParams) == 3 * 8 + 24 * 4  # 3 doubles, 17 floats, 7 int32
     assert C.sizeof(_lib.LgGraspResult) == 14 * 4
     assert C.sizeof(_lib.LgLeafStat) == 4 * 4 + 4 * 8 + 2 * 4
 
@@ -101,7 +101,23 @@ def test_image_processor_kernels(golden):
     np.testing.assert_array_equal(ip.get_kernel("sobel_x", "cpu").numpy(), golden["sobel_x"])
     np.testing.assert_array_equal(ip.get_kernel("sobel_y", "cpu").numpy(), golden["sobel_y"])
     dm = torch.from_numpy(golden["depth"] * golden["mask"].astype(np.float32))
-    np.testing.assert_allclose(ip.smooth_depth(dm, "cpu").numpy(), golden["smooth"], rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # smooth_depth runs in liblgrasp.so (test_gpu_parity.py)
+        ip.smooth_depth(dm, "cpu")
+    # the 1-D factor the library multiplies with reproduces the reference's 2-D kernels (image_processor.py:25-32)
+    from leafgrasp_amd.image_processor import flatness_config, gaussian_taps
+    r3 = np.load(os.path.join(REPO, "tests", "golden", "reference_vectors_r3.npz"))
+    for size, ref in ((5, golden["gaussian"]), (1, r3["gaussian_1"]), (3, r3["gaussian_3"]), (4, r3["gaussian_4"]), (7, r3["gaussian_7"])):
+        t = gaussian_taps(size).astype(np.float64)
+        np.testing.assert_allclose(np.outer(t, t), ref, rtol=3e-7, atol=1e-12)
+        assert flatness_config(L.ImageProcessor(96, 128, 21, size)) == size
+    bad = L.ImageProcessor(96, 128, 21, 5)
+    bad.kernels["gaussian"] = torch.ones(5, 5) / 25.0
+    with pytest.raises(ValueError, match="smoothing kernel"):
+        flatness_config(bad)
+    bad = L.ImageProcessor(96, 128, 21, 5)
+    bad.kernels["sobel_x"] = bad.kernels["sobel_x"] * 2
+    with pytest.raises(ValueError, match="Sobel"):
+        flatness_config(bad)
     assert ip.generate_color(3) == ip.generate_color(3)
     assert ip.calculate_centroid(torch.from_numpy(golden["mask"].astype(bool))) == pytest.approx((70.3, 50.2), abs=0.6)
 
@@ -146,6 +162,48 @@ def test_llava_scorer_fallback():
     assert s.evaluate_candidates(np.zeros((8, 8, 3), np.uint8), [{}, {}, {}]) == [0.5, 0.5, 0.5]   # llava_processor.py:35-36
     assert s._normalize_scores([0.2, 0.4, 0.6]) == pytest.approx([0.0, 0.5, 1.0])
     assert "Position: (3, 4)" in s._create_evaluation_prompt({"x": 3, "y": 4}, "pick")
+
+
+def test_llava_scorer_live_path_vs_reference_with_scripted_model():
+    """The generate -> decode -> split("assistant") -> float -> clip / 0.5 path (llava_processor.py:79-101), the prompt
+    (:54-77), _normalize_scores (:103-112) and get_confidence (:114-122) against what the REFERENCE class returned for the
+    same scripted (processor, model) pair (tests/golden/make_golden_r3.py; real weights do not exist here: LLaVA weights U)."""
+    from leafgrasp_amd.vla_scorer import LLaVAScorer
+    from scripted_llava import ScriptedModel, ScriptedProcessor
+    g = np.load(os.path.join(REPO, "tests", "golden", "reference_vectors_r3.npz"))
+    keys = [str(k) for k in g["llava_cand_keys"]]
+    cands = []
+    for row in g["llava_cands"]:
+        c = {k: (int(v) if k == "leaf_id" else float(v)) for k, v in zip(keys, row) if not np.isnan(v)}
+        cands.append(c)
+    script, instruction, image = [str(r) for r in g["llava_responses"]], str(g["llava_instruction"]), g["llava_image"]
+    s = LLaVAScorer(device="cpu", model_path=None)
+    assert [s._create_evaluation_prompt(c, instruction) for c in cands] == [str(p) for p in g["llava_prompts"]]
+    s.processor, s.model = ScriptedProcessor(script), ScriptedModel(script)
+    from PIL import Image
+    pil = Image.fromarray(np.ascontiguousarray(image[..., ::-1]))
+    raw = [s._evaluate_single_candidate(pil, str(p)) for p in g["llava_prompts"]]
+    assert raw == g["llava_raw"].tolist()                                   # incl. clip, parse failures and the raising generate()
+    assert sorted(f"{k}={v}" for k, v in s.model.kwargs[0].items()) == [str(k) for k in g["llava_generate_kwargs"]]
+    s.processor, s.model = ScriptedProcessor(script), ScriptedModel(script)
+    ev = s.evaluate_candidates(image, cands, instruction)
+    assert ev == pytest.approx(g["llava_eval"].tolist(), abs=0, rel=1e-15)
+    assert list(s.processor.prompts) == [str(p) for p in g["llava_prompts"]]
+    assert s.get_confidence(ev) == pytest.approx(float(g["llava_conf_of_eval"]), rel=1e-15)
+    script2 = [str(r) for r in g["llava_responses2"]]
+    s.processor, s.model = ScriptedProcessor(script2), ScriptedModel(script2)
+    ev2 = s.evaluate_candidates(image, cands[:3], instruction)
+    assert ev2 == pytest.approx(g["llava_eval2"].tolist(), rel=1e-15)
+    assert s.get_confidence(ev2) == pytest.approx(float(g["llava_conf_of_eval2"]), rel=1e-15)
+    assert s._normalize_scores(raw) == pytest.approx(g["llava_norm_of_raw"].tolist(), rel=1e-15)
+    assert s._normalize_scores([0.4, 0.4, 0.4]) == g["llava_norm_const"].tolist()
+    assert len(s._normalize_scores([])) == int(g["llava_norm_empty_len"]) and s.get_confidence([]) == float(g["llava_conf_empty"])
+    for row, exp in zip(g["llava_conf_cases_in"], g["llava_conf_cases_out"]):
+        assert s.get_confidence(list(row)) == pytest.approx(float(exp), rel=1e-15)
+    s.processor, s.model = ScriptedProcessor(script), ScriptedModel(script)
+    assert s.evaluate_candidates("not an image", cands[:4], instruction) == g["llava_eval_bad_image"].tolist()
+    s.model = None
+    assert s.evaluate_candidates(image, cands[:3], instruction) == g["llava_eval_no_model"].tolist()
 
 
 def test_harness_csv_format():
