@@ -484,14 +484,23 @@ def test_leaf_workspace_survives_a_change_of_aspect(L):
     """the leaf stage's bit rows are H x ceil(W / 64) words -- 480 x 640 needs 4800 per frame, 640 x 480 needs
     5120 at the same pixel count.  One handle, both shapes, either order: statistics and selection equal the oracle."""
     sel = L.OptimalLeafSelector(torch.device("cuda:0"))
-    for shape in ((480, 640), (640, 480), (600, 450), (480, 640), (300, 1000), (1000, 300)):
+    n_sel = 0
+    for shape in ((480, 640), (640, 480), (720, 960), (960, 720), (600, 450), (480, 640), (300, 1000), (1000, 300), (960, 720)):
         labels, depth, P = O.synthetic_scene(*shape, 7)
         sel.set_camera_params(P)
         ref = O.RefOptimalLeafSelector(field="edt")
         ref.set_camera_params(P)
-        assert sel.select_optimal_leaf(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda()) == \
-            ref.select_optimal_leaf(labels, depth), shape
-        assert sel.get_tall_leaves() == ref.get_tall_leaves()
+        exp = ref.select_optimal_leaf(labels, depth)
+        assert sel.select_optimal_leaf(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda()) == exp, shape
+        if exp is not None:   # (a frame without a 10000-px leaf leaves _tall_leaves at its previous value, leaf_scorer.py:144-146,174)
+            assert sel.get_tall_leaves() == ref.get_tall_leaves()
+            n_sel += 1
+        rows, _, _ = sel.leaf_statistics(torch.from_numpy(labels).cuda(), torch.from_numpy(depth).cuda())
+        assert [r["id"] for r in rows] == np.unique(labels)[1:].tolist()
+        for r in rows:
+            lm = labels == r["id"]
+            assert r["area"] == int(lm.sum()) and r["median_depth"] == np.median(depth[lm])
+    assert n_sel >= 3
 
 
 def test_leaf_selection_batch_equals_per_frame(L):
