@@ -39,9 +39,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LG_W4_S3 0
 #define LG_W4_S4 3
 #endif
+#ifndef LG_W4_NT
+#define LG_W4_NT 0    // 1: non-temporal plane stores in lg_wino4_kernel's epilogue (same results)
+#endif
 #ifndef LG_W4_EXP
 #define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
-#endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results)
+#endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results),
+                      //   256 epilogue arithmetic without its stores, 512 stores into one small region,
+                      //   2048 / 4096 no stores from the staging / the transform waves
 
 namespace {
 
@@ -593,11 +598,12 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     // input rows come from HBM (the previous layer's output, GBs per layer): with 3 stages the transfers of chunk q + 3 are
     // issued during chunk q and only have to land by the END of chunk q + 1 (a counted vmcnt wait leaves them in flight across
     // one barrier); with 2 stages they have to land within the chunk that issues them and every chunk pays an HBM round trip.
-    constexpr int NSTG = (2 * ABLK + 2 * VBLK + 3 * STAGE) * 4 <= 160 * 1024 ? 3 : 2;
-    __shared__ __attribute__((aligned(16))) float s_mem[2 * ABLK + 2 * VBLK + NSTG * STAGE];
+    constexpr int NSTG = (2 * ABLK + 2 * VBLK + 3 * STAGE + COUT) * 4 <= 160 * 1024 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float s_mem[2 * ABLK + 2 * VBLK + NSTG * STAGE + COUT];
     float* const s_a = s_mem;
     float* const s_v = s_mem + 2 * ABLK;
     float* const s_in = s_mem + 2 * ABLK + 2 * VBLK;
+    float* const s_bias = s_in + NSTG * STAGE;             // the layer's (BN-folded) biases
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             }
         };
 
-        // ---- prologue: chunk 0 staged and transformed, chunk 1's input under way
+        // ---- prologue: chunk 0 staged and transformed, the U block of chunk 1 and the inputs of chunks 1, 2 under way
         if (!IS_T) {
             set_input_item(0);
 #pragma unroll
@@ -764,7 +770,8 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 9; j++) a_piece(j, ablk0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i = t; i < COUT; i += 512) s_bias[i] = bias[i];   // (read back at every item start: LDS, no vmcnt involved)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (IS_T) {
             f32x4 dl[5];
             f32x2 dh[5];
@@ -776,6 +783,9 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < NIN; j++) input_piece(j, 1);
                 input_advance();
+                const float* ablk1 = U4 + (size_t)item_at(0).cob * ABLK + (size_t)NCB * ABLK;   // (NC >= 3: chunk 1 is item 0's)
+#pragma unroll
+                for (int j = 0; j < 9; j++) a_piece(j, ablk1, 1);
             }
             if (NSTG == 3 && Q > 2) {   // chunk 2 may stay in flight across the barrier
 #pragma unroll
@@ -788,24 +798,46 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         }
         asm volatile("s_barrier" ::: "memory");
 
+        // ---- main pipeline.  One iteration = one chunk q (A / V stage st = q & 1):
+        //        [T: load the input rows of chunk q + 1]  MM 0..1  [T: transform -> V[st ^ 1]]  MM 2..3  [S: input DMA of chunk
+        //        q + 3]  MM 4..5, fragment reads of groups 6..8 -> registers, WAIT, BARRIER(q), [S: U block of chunk q + 2 -> A[st]]
+        //        MM 6..8 interleaved with the fragment reads of groups 0..2 of chunk q + 1.
+        //      The barrier sits INSIDE the chunk's MFMA sequence: when it falls every wave holds the operands of three more MFMA
+        //      groups in registers, so neither the arrival skew of the eight waves nor the LDS latency of the next chunk's first
+        //      fragments leaves the matrix pipe idle (at a chunk boundary all eight waves asked for their first fragments at once
+        //      and waited for them: tools/cnn_layers.sh, r3).  What barrier(q) promises: every read of A[st] / V[st] has returned
+        //      (lgkmcnt(0) of every wave), V[st ^ 1] is written, U(q + 1) and the inputs of chunk q + 2 have landed.
+        //      Stores: a wave's plane stores at an item's end are younger than the U block it asked for right after the barrier
+        //      before them, so the staging waves' wait at the next barrier can leave them in flight (vmcnt counts in order; on
+        //      this part loads and stores share the counter) -- a store's round trip under a write-heavy layer is longer than a chunk.
+        constexpr int SCNT = 4 * (POOL ? 2 : 4);                // plane-store instructions of one epilogue that are always issued
         int q = 0;                                              // chunk counter over all items (stage parity)
+        f32x4 fa[3] = {}, fb[3] = {};
+#define LG_FRAG_AT(PG, AP, BP) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], AP); lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], BP); }
+        {
+            const unsigned ap0 = (unsigned)(size_t)a_rd, bp0 = (unsigned)(size_t)b_rd;
+            LG_FRAG_AT(0, ap0, bp0); LG_FRAG_AT(1, ap0, bp0); LG_FRAG_AT(2, ap0, bp0);
+        }
+        bool prev_full = false;                                 // the previous item's epilogue issued its SCNT stores (wave-uniform)
+        f32x4 acc[36];
+#pragma unroll
+        for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[item_at(0).cob * 64 + 16 * cb + 4 * (lane >> 4)]);
 #pragma unroll 1
         for (int it_i = 0; it_i < ni; it_i++) {
             const Item cur = item_at(it_i);
             const int cob_next = it_i + 1 < ni ? item_at(it_i + 1).cob : cur.cob;
-            f32x4 acc[36];
-#pragma unroll
-            for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int c = 0; c < NC; c++, q++) {
                 const int st = q & 1;                           // A / V stage of this chunk
                 const int in_next = NSTG == 3 ? (q + 1) % 3 : st ^ 1;   // input stage holding chunk q + 1 (transformed now)
                 const int in_free = NSTG == 3 ? q % 3 : st;             // input stage the staging waves refill (chunk q + NSTG)
-                // Fragment ring: position group pg uses slot pg % 3, its reads are issued two groups ahead of its MFMAs; every
-                // wait leaves the (up to) 4 fragment reads issued after the awaited pair in flight.
-                f32x4 fa[3] = {}, fb[3] = {};
+                // Fragment ring: position group pg uses slot pg % 3, its reads are issued two groups ahead of its MFMAs (groups 0..2
+                // in the previous iteration); every wait leaves the (up to) 4 fragment reads issued after the awaited pair in flight.
                 const unsigned ap = (unsigned)(size_t)(a_rd + st * ABLK), bp = (unsigned)(size_t)(b_rd + st * VBLK);
-#define LG_FRAG(PG) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], ap); lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], bp); }
+                const unsigned apn = (unsigned)(size_t)(a_rd + (st ^ 1) * ABLK), bpn = (unsigned)(size_t)(b_rd + (st ^ 1) * VBLK);
+                const bool has_next = q + 1 < Q;
+#define LG_FRAG(PG) LG_FRAG_AT(PG, ap, bp)
 #define LG_MM(PG)                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     if (!(LG_W4_EXP & 32)) _Pragma("unroll") for (int e = 0; e < 4; e++)                                                 \
@@ -815,7 +847,6 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     f32x4 dl[5];
                     f32x2 dh[5];
                     transform_load(in_next, dl, dh);             // (after the very last chunk: stale bytes into an unused V stage)
-                    LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
                     LG_FRAG(3);
                     lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
@@ -830,56 +861,58 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     LG_FRAG(7);
                     lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
                     LG_FRAG(8);
-                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
-                    lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
-                    lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+                    // (no vmcnt: these waves issue plane stores only, nothing they wait for)
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]), "+v"(fa[2]), "+v"(fb[2])::"memory");
                 } else {
-                    // the next chunk's U block (9 transfers), then the input NSTG chunks ahead (NIN transfers); schedule: LG_W4_S*
-                    const bool more = q + 1 < Q, more2 = q + NSTG < Q;
-                    const float* ablk = U4 + (size_t)(c + 1 < NC ? cur.cob : cob_next) * ABLK + (size_t)(c + 1 < NC ? c + 1 : 0) * NCB * ABLK;
-                    constexpr int NT = 9 + NIN;                  // transfers per chunk and staging wave
-                    auto xfer = [&](int k0, int k1) {            // transfers k0 .. k1 - 1 of the chunk's list: A first, then input
-#pragma unroll
-                        for (int k = k0; k < k1 && k < NT; k++) {
-                            if (k < 9) { if (more) a_piece(k, ablk, st ^ 1); }
-                            else if (more2) input_piece(k - 9, in_free);   // read by the transform of chunk q, one iteration ago
-                        }
-                    };
-                    // transfers (9 of U, then NIN of input) per slot: before the first MFMA group, then after groups 0..4
-                    constexpr int C0 = LG_W4_S0, C1 = C0 + LG_W4_S1, C2 = C1 + LG_W4_S2, C3 = C2 + LG_W4_S3, C4 = C3 + LG_W4_S4;
-                    xfer(0, C0);
-                    LG_FRAG(0); LG_FRAG(1); LG_FRAG(2);
+                    const bool more2 = q + NSTG < Q;
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
-                    xfer(C0, C1);
                     LG_FRAG(3);
                     lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(1);
-                    xfer(C1, C2);
                     LG_FRAG(4);
                     lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(2);
-                    xfer(C2, C3);
                     LG_FRAG(5);
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(3);
-                    xfer(C3, C4);
+                    if (more2) {                                 // input rows NSTG chunks ahead: the stage the transform of chunk q read
+#pragma unroll
+                        for (int k = 0; k < NIN; k++) input_piece(k, in_free);
+                        input_advance();
+                    }
                     LG_FRAG(6);
                     lg_lds_wait2<4>(fa[1], fb[1]); LG_MM(4);
-                    xfer(C4, NT);
-                    if (more2) input_advance();
                     LG_FRAG(7);
                     lg_lds_wait2<4>(fa[2], fb[2]); LG_MM(5);
                     LG_FRAG(8);
-                    lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(6);
-                    lg_lds_wait2<2>(fa[1], fb[1]); LG_MM(7);
-                    lg_lds_wait2<0>(fa[2], fb[2]); LG_MM(8);
+                    // U(q + 1) (asked for right after the previous barrier) and everything older have landed; what may stay in
+                    // flight is younger: the NIN input transfers above (3-stage ring) and, in an item's first chunk, the previous
+                    // item's plane stores
+                    const bool keep_in = NSTG == 3 && more2, keep_st = NSTG == 3 && c == 0 && prev_full;
+                    // (the vmcnt waits carry no register operands: tying the fragment registers to four alternative asm statements made
+                    //  hipcc copy them -- destinations of LDS reads still in flight -- in front of the wait)
+                    if (keep_in && keep_st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCNT + NIN) : "memory");
+                    else if (keep_st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCNT) : "memory");
+                    else if (keep_in) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIN) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]), "+v"(fa[2]), "+v"(fb[2])::"memory");
+                    if (q + 2 < Q) {                             // the U block two chunks ahead into the stage this chunk has just released
+                        const bool same = c + 2 < NC;
+                        const float* ablk = U4 + (size_t)(same ? cur.cob : cob_next) * ABLK + (size_t)(same ? c + 2 : c + 2 - NC) * NCB * ABLK;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) a_piece(k, ablk, st);
+                    }
                 }
+                LG_MM(6);
+                if (has_next) { LG_FRAG_AT(0, apn, bpn); }
+                LG_MM(7);
+                if (has_next) { LG_FRAG_AT(1, apn, bpn); }
+                LG_MM(8);
+                if (has_next) { LG_FRAG_AT(2, apn, bpn); }
 #undef LG_FRAG
 #undef LG_MM
-                // staging waves: the U block of the next chunk (and everything older) has landed; with 3 input stages the NIN
-                // input transfers just issued (the youngest) stay in flight across the barrier
-                if (!IS_T && NSTG == 3 && q + NSTG < Q) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NIN) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
 
-            // ---- item done: Y = A^T M A (4x4 from 6x6), bias, ReLU (+ 2x2 max-pool); interior of the haloed output plane
+            // ---- item done: Y = A^T M A (4x4 from 6x6), ReLU (+ 2x2 max-pool); interior of the haloed output plane.  The bias is
+            //      already in: column 1 of A^T is all ones, so a constant b in M[1][1] adds b to each of the 16 outputs -- the
+            //      accumulator of position (1,1) starts from the bias instead of 0 (one LDS read per item instead of 64 adds).
             constexpr int WO = POOL ? WI / 2 : WI;
             constexpr int OP = OUT_HALO ? lg_wp(WO) : WO;
             constexpr int OPL = OUT_HALO ? lg_plane(WO) : WO * WO;
@@ -888,6 +921,10 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             const int epb = etau / TPB, etl = etau % TPB;
             const int n = cur.n0 + epb;
             const int trg = cur.band * TROWS + etl / TC, tcg = etl % TC;
+            if (LG_W4_EXP & 64) {
+#pragma unroll
+                for (int p = 0; p < 36; p++) asm volatile("" ::"v"(acc[p]));
+            } else
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
@@ -902,18 +939,21 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     s[2][j] = fmaf(4.f, t3, t1);
                     s[3][j] = fmaf(8.f, t4, t2) + m5;
                 }
-                const float bv = bias[co];
                 float y[4][4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
-                    y[p][0] = s[p][0] + t1 + t3 + bv;
-                    y[p][1] = fmaf(2.f, t4, t2) + bv;
-                    y[p][2] = fmaf(4.f, t3, t1) + bv;
-                    y[p][3] = fmaf(8.f, t4, t2) + s[p][5] + bv;
+                    y[p][0] = s[p][0] + t1 + t3;
+                    y[p][1] = fmaf(2.f, t4, t2);
+                    y[p][2] = fmaf(4.f, t3, t1);
+                    y[p][3] = fmaf(8.f, t4, t2) + s[p][5];
                 }
-                if (n < N) {
+                if ((LG_W4_EXP & 256) || ((LG_W4_EXP & 2048) && !IS_T) || ((LG_W4_EXP & 4096) && IS_T)) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) asm volatile("" ::"v"(y[p][0]), "v"(y[p][1]), "v"(y[p][2]), "v"(y[p][3]));
+                } else if (n < N) {
                     float* o = out + ((size_t)n * COUT + co) * OPL + OO;
+                    if (LG_W4_EXP & 512) o = out + (size_t)(co & 63) * OPL + OO;   // ablation: every item stores into the same 64 planes (L2 hits)
                     // One vector store per tile row (interior pixels start at an odd column: 4-byte aligned 8 / 16-byte stores,
                     // which the hardware takes): a wave instruction covers whole 64-128-byte runs of the plane.
                     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -923,12 +963,15 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                         for (int p = 0; p < 2; p++) {
                             const float v0 = fmaxf(fmaxf(fmaxf(y[2 * p][0], y[2 * p][1]), fmaxf(y[2 * p + 1][0], y[2 * p + 1][1])), 0.f);
                             const float v1 = fmaxf(fmaxf(fmaxf(y[2 * p][2], y[2 * p][3]), fmaxf(y[2 * p + 1][2], y[2 * p + 1][3])), 0.f);
-                            *reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg) = (f32x2u){v0, v1};
+                            if (LG_W4_NT) __builtin_nontemporal_store((f32x2u){v0, v1}, reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg));
+                            else *reinterpret_cast<f32x2u*>(o + (2 * trg + p) * OP + 2 * tcg) = (f32x2u){v0, v1};
                         }
                     } else {
 #pragma unroll
                         for (int p = 0; p < 4; p++)
-                            *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
+                            if (LG_W4_NT) __builtin_nontemporal_store((f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)},
+                                                                      reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg));
+                            else *reinterpret_cast<f32x4u*>(o + (4 * trg + p) * OP + 4 * tcg) =
                                 (f32x4u){fmaxf(y[p][0], 0.f), fmaxf(y[p][1], 0.f), fmaxf(y[p][2], 0.f), fmaxf(y[p][3], 0.f)};
                     }
                     // The halo around the interior is (and stays) zero, and is written all the same: a cache line that keeps
@@ -960,6 +1003,10 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
             }
+            prev_full = cur.n0 + PB <= N;            // every lane of this wave stored (n < N): the SCNT stores above were issued
+#pragma unroll
+            for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[cob_next * 64 + 16 * cb + 4 * (lane >> 4)]);
         }
     };
     if (wave < 4) role(std::true_type{});
