@@ -45,6 +45,12 @@ def _cpu_share():
 
 
 N_DISTINCT = 32  # distinct synthetic scenes in the benchmark batch (the batch cycles through them)
+# the other BASELINE.json configs, measured outside the headline's timed region: name -> (H, W, frames per step, distinct scenes)
+SECONDARY_CONFIGS = {
+    "720p_b256": (720, 1280, 256, 16),       # configs[0]'s frame size (the reference's CPU-runnable case) on the HIP path
+    "4k_b64": (2160, 3840, 64, 8),           # configs[3]: LDS-tiled SDF + distance-transform stress
+    "1080p_b32": (1080, 1920, 32, 32),       # configs[2]'s per-GPU share: 256 frames sharded over 8 GPUs
+}
 
 
 def _scene(args):
@@ -130,6 +136,107 @@ def cpu_baseline(H, W, P, params, n_frames, threads):
     return times, serial
 
 
+def _time_config(dev, L, lib, params, P, m_np, d_np, B, H, W, steps):
+    """fps, ms per step, per-kernel ms and the plane kernel's fraction of the HBM peak for B frames of H x W on a fresh handle."""
+    sel = L.GraspPointSelector(dev, load_model=False)
+    sel.set_camera_params(P)
+    sel.set_cnn_state_dict(params)
+    m, d = torch.from_numpy(m_np).to(dev), torch.from_numpy(d_np).to(dev)
+    for _ in range(2):
+        res = sel.select_grasp_points_batch(m, d)
+    lib.lg_profile_enable(sel._h, 1)
+    sel.select_grasp_points_batch(m, d)
+    torch.cuda.synchronize(dev)
+    kern = {}
+    for name in ("prep", "bbox", "orient", "stem", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        lib.lg_profile_read(sel._h, name.encode(), C.byref(n), C.byref(ms))
+        if n.value:
+            kern[name] = round(ms.value / n.value, 4)
+    lib.lg_profile_enable(sel._h, 2)
+    sel.select_grasp_points_batch(m, d)
+    lib.lg_profile_enable(sel._h, 2)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = sel.select_grasp_points_batch(m, d)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    n, ms = C.c_int(0), C.c_double(0.0)
+    lib.lg_profile_read(sel._h, b"final", C.byref(n), C.byref(ms))
+    lib.lg_profile_enable(sel._h, 0)
+    nd = min(B, len(m_np))
+    wins = [sel.dt_maxima(i)[2] for i in range(nd)]
+    launch_bytes = final_kernel_bytes(m_np[:nd], wins, H, W) * (B / nd)
+    final_ms = ms.value / max(1, n.value)
+    kern["final"] = round(final_ms, 4)
+    return {"value": round(B / dt, 1), "unit": "frames/s", "frames_per_step": B, "height": H, "width": W, "steps": steps,
+            "ms_per_step": round(1e3 * dt, 4), "found": sum(r[0] is not None for r in res),
+            "final_frac_of_hbm_peak": round(launch_bytes / (final_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "final_bytes_per_px": round(launch_bytes / (B * H * W), 3), "kernels_ms": kern,
+            "path_hbm_frac": round(B / dt * PATH_BYTES_PER_PX * H * W / (HBM_PEAK_GBS * 1e9), 5)}
+
+
+def secondary_configs(args, dev, L, lib, SI, params, P, extra_frames, masks_np, depths_np, labels_np, H, W):
+    """The other BASELINE.json configs and the reference's own call pattern (one frame per call), all outside the headline's
+    timed region.  Same workload definition as the headline (8 planes + valid + top-20 + fp32 CNN on 20 candidates)."""
+    out = {}
+    for name, (h2, w2, b2, nd2) in SECONDARY_CONFIGS.items():
+        try:
+            if (h2, w2) == (H, W):
+                m_np, d_np, P2 = masks_np[:b2], depths_np[:b2], P
+                if len(m_np) < b2:
+                    continue
+            else:
+                m_np, d_np, P2, _ = extra_frames[name]
+            out[name] = _time_config(dev, L, lib, params, P2, m_np, d_np, b2, h2, w2, args.config_steps)
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)}
+    if "1080p_b32" in out and "value" in out["1080p_b32"]:
+        out["1080p_b32"]["what"] = ("BASELINE config 3 read literally (256 frames sharded over 8 GPUs = 32 per GPU, strong scaling): "
+                                    "8 x this value is the 8-GPU figure when nothing but the frames is shared; the headline `value` is "
+                                    "weak scaling at 256 frames per GPU")
+    # the reference's call pattern: ONE frame per select_grasp_point call (leaf_grasp_node_v3.py:102-158), tensors resident
+    try:
+        sel = L.GraspPointSelector(dev, load_model=False)
+        sel.set_camera_params(P)
+        sel.set_cnn_state_dict(params)
+        ip = L.ImageProcessor(H, W, 21, 5)
+        m1, d1 = torch.from_numpy(masks_np[0]).to(dev), torch.from_numpy(depths_np[0]).to(dev)
+        for _ in range(5):
+            sel.select_grasp_point(m1, d1, ip)
+        ts = []
+        for _ in range(40):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            r1 = sel.select_grasp_point(m1, d1, ip)
+            ts.append(time.perf_counter() - t0)
+        hz = L.LeafGraspHarness(H, W, dev, load_model=False)
+        hz.camera_info_callback(np.asarray(P).reshape(-1))
+        hz.grasp_selector.set_cnn_state_dict(params)
+        hz.latest_mask, hz.latest_depth = torch.from_numpy(labels_np[0]).to(dev), d1
+        for _ in range(3):
+            hz.select_optimal_leaf()
+        tn = []
+        for _ in range(20):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            csv = hz.select_optimal_leaf()
+            tn.append(time.perf_counter() - t0)
+        out["1080p_b1_latency_ms"] = {"select_grasp_point": round(1e3 * float(np.median(ts)), 4),
+                                      "select_grasp_point_min": round(1e3 * float(np.min(ts)), 4),
+                                      "node_sequence": round(1e3 * float(np.median(tn)), 4), "found": r1[0] is not None and csv is not None,
+                                      "what": "median wall time of one call on one resident frame (label / mask + depth tensors on the "
+                                              "device): GraspPointSelector.select_grasp_point incl. CNN, and the node's whole "
+                                              "select_optimal_leaf sequence (leaf selection + grasp selection)"}
+        hz = sel = None
+    except Exception as e:  # noqa: BLE001
+        out["1080p_b1_latency_ms"] = {"error": str(e)}
+    import gc
+    gc.collect()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +263,11 @@ def main():
     ap.add_argument("--h2d-steps", type=int, default=3,
                     help="N=1 only: steps of pinned-host -> device copy of depth + mask followed by the scoring pass, reported "
                          "as `h2d_inclusive` (never `value`; 0 = skip)")
+    ap.add_argument("--pipelined", type=int, default=2,
+                    help="N=1 only: batches in flight for the secondary `pipelined` figure (the headline keeps --inflight; <= 1 = skip)")
+    ap.add_argument("--config-steps", type=int, default=5,
+                    help="N=1 only: timed steps per entry of the secondary `configs` leg (720p x 256, 4K x 64, 1080p x 32 = config 3's "
+                         "per-GPU share, and single-frame latency of select_grasp_point / the node sequence; 0 = skip)")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: print every step's wall time to stderr "
                                                             "(adds a device sync per step; not the headline mode)")
     args = ap.parse_args()
@@ -166,7 +278,14 @@ def main():
     # synthetic frames first: the scene generator forks worker processes, which must happen before this process touches the GPU
     H, W, B = args.height, args.width, args.batch
     cpu_share = _cpu_share()
-    masks_np, depths_np, P, labels_np = make_frames(B, H, W, workers=max(1, min(8, cpu_share // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+    gen_workers = max(1, min(8, cpu_share // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    masks_np, depths_np, P, labels_np = make_frames(B, H, W, workers=gen_workers)
+    # frames of the other BASELINE configs (secondary `configs` leg, N=1 only): generated here, before the process touches the GPU
+    extra_frames = {}
+    if world == 1 and args.config_steps > 0 and not args.no_cnn:
+        for name, (h2, w2, b2, nd2) in SECONDARY_CONFIGS.items():
+            if (h2, w2) != (H, W):
+                extra_frames[name] = make_frames(b2, h2, w2, n_distinct=nd2, workers=gen_workers)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -323,7 +442,11 @@ def main():
                 traffic = None
             out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "bytes_per_launch": round(launch_bytes),
+                               "traffic": traffic,
+                               "traffic_source": "profiles/r02_pmc_counters.json: rocprofv3 --pmc passes of a 32-frame 1080p launch of this "
+                                                 "kernel (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_final.sh), bytes per pixel x this "
+                                                 "launch's pixels -- NOT counted during this run",
+                               "bytes_per_launch": round(launch_bytes),
                                "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX,
                                "distinct_scenes": n_distinct}
         if "cnn" in kern and not args.no_cnn:
@@ -411,6 +534,64 @@ def main():
                 dsel = dm = dd = None
             except Exception as e:  # noqa: BLE001
                 out["roofline_dense"] = {"error": str(e)}
+        if world == 1 and args.pipelined > 1 and len(sels) == 1 and not args.no_cnn:
+            # secondary figure (never `value`): the same steps with several batches in flight -- one handle, stream and host thread
+            # each, all on this GPU -- so that one batch's latency-bound stages (sweeps, top-k: one workgroup per frame) and host work
+            # run beside another batch's CNN / plane kernels.  The stretched per-kernel times show what the overlap costs.
+            try:
+                psels, pstreams = list(sels), list(streams)
+                while len(psels) < args.pipelined:
+                    ps_ = L.GraspPointSelector(dev, load_model=False)
+                    ps_.set_camera_params(P)
+                    ps_.set_cnn_state_dict(params)
+                    psels.append(ps_)
+                    pstreams.append(torch.cuda.Stream(dev))
+                plast = [None] * len(psels)
+
+                def prun(n_steps):
+                    def worker(i):
+                        torch.cuda.set_device(dev)
+                        with torch.cuda.stream(pstreams[i]):
+                            for _ in range(i, n_steps, len(psels)):
+                                plast[i] = psels[i].select_grasp_points_batch(masks, depths)
+                    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(psels))]
+                    for t_ in th:
+                        t_.start()
+                    for t_ in th:
+                        t_.join()
+                prun(2 * len(psels))
+                for ps_ in psels:
+                    lib.lg_profile_enable(ps_._h, 1)
+                prun(2 * len(psels))
+                torch.cuda.synchronize(dev)
+                pk = {}
+                for name in ("dt_fwd", "dt_bwd", "final", "topk", "gather", "cnn"):
+                    tn_, tm_ = 0, 0.0
+                    for ps_ in psels:
+                        n_, ms_ = C.c_int(0), C.c_double(0.0)
+                        lib.lg_profile_read(ps_._h, name.encode(), C.byref(n_), C.byref(ms_))
+                        tn_ += n_.value
+                        tm_ += ms_.value
+                    if tn_:
+                        pk[name] = round(tm_ / tn_, 4)
+                for ps_ in psels:
+                    lib.lg_profile_enable(ps_._h, 0)
+                prun(len(psels))
+                torch.cuda.synchronize(dev)
+                t_p = time.perf_counter()
+                prun(args.steps)
+                torch.cuda.synchronize(dev)
+                dt_p = time.perf_counter() - t_p
+                same = all(r == res for r in plast if r is not None)
+                out["pipelined"] = {"value": round(B * args.steps / dt_p, 2), "unit": "frames/s", "batches_in_flight": len(psels),
+                                    "steps": args.steps, "ms_per_step": round(1e3 * dt_p / args.steps, 4),
+                                    "vs_single": round(B * args.steps / dt_p / fps, 4), "results_equal_single": bool(same),
+                                    "kernels_ms_stretched": pk}
+                psels = pstreams = plast = None
+            except Exception as e:  # noqa: BLE001
+                out["pipelined"] = {"error": str(e)}
+        if world == 1 and args.config_steps > 0 and not args.no_cnn:
+            out["configs"] = secondary_configs(args, dev, L, lib, SI, params, P, extra_frames, masks_np, depths_np, labels_np, H, W)
         if world == 1 and args.h2d_steps > 0 and not args.no_cnn:
             # secondary figure (never `value`, SURVEY 8d "Timing method"): the same scoring pass with depth f32 + mask u8 arriving
             # from PINNED host memory every step (10.4 MB per 1080p frame over PCIe Gen5)

@@ -78,6 +78,8 @@ struct lg_ctx {
                                    // side stream behind the orientation kernel; 2: on a third stream
     std::string orient_note;       // why the device-side orientation scratch could not be set up (host analysis is used then)
     std::atomic<bool> busy{false}; // one call in flight per handle (SURVEY 8b "Threading"): a concurrent second call gets LG_ERR_BUSY
+    hipStream_t s_cnn = nullptr;   // LG_CNN_CUS=n: the CNN runs on a stream of its own restricted to n CUs (experiment: room for a second
+    hipEvent_t ev_cnn0 = nullptr, ev_cnn1 = nullptr;   // batch's memory-bound kernels beside it, bench.py --inflight)
     bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
@@ -336,6 +338,22 @@ int lg_create(int device, lg_handle* out) {
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("LG_CNN_CUS")) {
+        const int n = atoi(e);
+        int total = 0;
+        hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, device);
+        if (n >= 8 && n < total) {
+            // the CU mask's bits are dealt round-robin to the XCDs: the first n bits = n / 8 CUs on each of the 8 XCDs
+            uint32_t mask[16] = {0};
+            for (int i = 0; i < n / 8 * 8; i++) mask[i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&h->s_cnn, (total + 31) / 32, mask) == hipSuccess &&
+                hipEventCreateWithFlags(&h->ev_cnn0, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&h->ev_cnn1, hipEventDisableTiming) == hipSuccess)
+                h->cnn.max_cus = n / 8 * 8;
+            else
+                h->s_cnn = nullptr;
+        }
+    }
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
     *out = h;
     return LG_OK;
@@ -358,8 +376,10 @@ int lg_destroy(lg_handle h) {
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     if (h->ev_begin) hipEventDestroy(h->ev_begin);
-    for (hipStream_t q : {h->s_dt[0], h->s_dt[1], h->s_main, h->s_topk})
+    for (hipStream_t q : {h->s_dt[0], h->s_dt[1], h->s_main, h->s_topk, h->s_cnn})
         if (q) hipStreamDestroy(q);
+    if (h->ev_cnn0) hipEventDestroy(h->ev_cnn0);
+    if (h->ev_cnn1) hipEventDestroy(h->ev_cnn1);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
     if (h->ev_copy) hipEventDestroy(h->ev_copy);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
@@ -952,9 +972,21 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                                  h->cand_n + off, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, sM);
             }
             std::string err;
-            ProfScope ps(h, "cnn", sM);
-            int r2 = lg_cnn_run(&h->cnn, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, n * K, h->logits + (size_t)off * K, sM, &err);
-            if (r2) return fail(h, r2, err.c_str());
+            hipStream_t sC = sM;
+            if (h->s_cnn) {   // experiment: the CNN on its CU-masked stream, ordered after the gather and before the copy-back
+                sC = h->s_cnn;
+                LG_HIP(h, hipEventRecord(h->ev_cnn0, sM));
+                LG_HIP(h, hipStreamWaitEvent(sC, h->ev_cnn0, 0));
+            }
+            {
+                ProfScope ps(h, "cnn", sC);
+                int r2 = lg_cnn_run(&h->cnn, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, n * K, h->logits + (size_t)off * K, sC, &err);
+                if (r2) return fail(h, r2, err.c_str());
+            }
+            if (h->s_cnn) {
+                LG_HIP(h, hipEventRecord(h->ev_cnn1, sC));
+                LG_HIP(h, hipStreamWaitEvent(sM, h->ev_cnn1, 0));
+            }
         }
         return LG_OK;
     };

@@ -12,6 +12,7 @@ struct RtLayer { int cin, cout, cinp, coutp, wi; bool pool; };   // real / padde
 
 struct LgCnn {
     bool loaded = false;
+    int max_cus = 0;              // > 0: the persistent conv kernels take this many workgroups (CUs) instead of all (LG_CNN_CUS experiment)
     int n_layers = 6;             // 2 conv layers per encoder block
     RtLayer layers[8] = {};
     bool standard = true;         // encoder [64,128,256]: the direct kernels / A-B switches exist for this one only

@@ -1174,6 +1174,7 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const f
 }
 
 #define LG_WINO4_L0_SHAPES(X) X(12, 64, 32, false) X(12, 128, 32, false)
+int g_wino4_cus = 0;   // > 0: workgroups (= CUs) the persistent F(4x4) kernels may take (set per call from LgCnn::max_cus; experiment)
 bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
                      float* out, int N, hipStream_t s) {
     const int tp = (wi / 4) * (wi / 4);
@@ -1185,7 +1186,8 @@ bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const 
         return n >= 8 ? n / 8 * 8 : 8;
     }();
     const long long items8 = (long long)((ntb + 7) / 8) * (cout / 64);   // items per XCD
-    const int grid = 8 * (int)std::min<long long>(items8, num_cu / 8);
+    const int cus = g_wino4_cus > 0 ? std::max(8, std::min(num_cu, g_wino4_cus / 8 * 8)) : num_cu;
+    const int grid = 8 * (int)std::min<long long>(items8, cus / 8);
 #define X(CI, CO, W_, P)                                                                                              \
     if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
         constexpr bool CM = 36LL * CI * CO * 4 > 3 * 1024 * 1024;                                                     \
@@ -1440,6 +1442,7 @@ int lg_cnn_run(LgCnn* c, const float* patches, bool haloed_in, int N, float* log
 static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err) {
     int rc = ensure_act(c, N, s, err);
     if (rc) return rc;
+    g_wino4_cus = c->max_cus;
     const float* x = patches;
     if (!haloed_in) {   // the C-ABI's dense [N][9][32][32] patches -> haloed planes
         hipLaunchKernelGGL(lg_repack_kernel, dim3((unsigned)(N * 9)), dim3(256), 0, s, patches, c->in_halo, (long long)N * 9);
