@@ -63,7 +63,7 @@ struct lg_ctx {
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
-    hipEvent_t ev_orient = nullptr, ev_side = nullptr;
+    hipEvent_t ev_orient = nullptr, ev_side = nullptr, ev_export = nullptr;
     int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -76,6 +76,7 @@ struct lg_ctx {
     bool opt_nt_stores = false;  // LG_NT_STORES: non-temporal plane stores (measured slower)
     int opt_side_tail = 1;         // LG_SIDE_TAIL=0: frame-border maxima + stem bits after the sweeps on the caller's stream (round 1); 1: on the
                                    // side stream behind the orientation kernel; 2: on a third stream
+    bool export_pending = false;   // this call's bit-row export has not been queued yet (enq_export)
     std::string orient_note;       // why the device-side orientation scratch could not be set up (host analysis is used then)
     std::atomic<bool> busy{false}; // one call in flight per handle (SURVEY 8b "Threading"): a concurrent second call gets LG_ERR_BUSY
     hipStream_t s_cnn = nullptr;   // LG_CNN_CUS=n: the CNN runs on a stream of its own restricted to n CUs (experiment: room for a second
@@ -306,7 +307,8 @@ int lg_create(int device, lg_handle* out) {
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_export, hipEventDisableTiming) != hipSuccess) {
         g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
@@ -372,6 +374,7 @@ int lg_destroy(lg_handle h) {
     lg_orient_free(h->orient);
     if (h->ev_orient) hipEventDestroy(h->ev_orient);
     if (h->ev_side) hipEventDestroy(h->ev_side);
+    if (h->ev_export) hipEventDestroy(h->ev_export);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -463,7 +466,8 @@ int enq_tail(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
 }
 
 // pack bits + D2H of the bit rows on the copy stream
-int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_t ev_prep, hipEvent_t ev_copy) {
+int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_t ev_prep) {
+    h->export_pending = true;
     const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
     LG_HIP(h, hipMemsetAsync(h->maxfix + 2 * (size_t)off, 0, sizeof(uint32_t) * 2 * n, s));
     {
@@ -495,13 +499,25 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
         if (rc) return rc;
         LG_HIP(h, hipEventRecord(h->ev_side, ts));
     }
+    return LG_OK;
+}
+
+// Bit rows of the bounding boxes + the windows to the host (pre-grasp clearance probes at the end of lg_select_grasp; contour
+// analysis of frames the device kernel hands back).  `after`: an event on the caller's stream the export has to wait for --
+// the export writes pinned host memory over PCIe and slows every memory-bound kernel beside it about 4x (the sweeps' share of
+// the step went 0.26 -> 0.52 ms with it running beside them), so lg_select_grasp queues it behind the top-k, beside the
+// MFMA-bound CNN, instead of beside the sweeps; nullptr: right away (somebody is about to wait for it).
+int enq_export(lg_ctx* h, const Plan& pl, int off, int n, hipEvent_t after) {
+    const size_t words = (size_t)pl.H * pl.WW;
+    if (after) LG_HIP(h, hipStreamWaitEvent(h->copy_stream, after, 0));
     if (h->bits_host_dev)   // rows of the bounding boxes only, posted writes by a small grid on the priority stream
         lg_launch_export_rows(h->bits + off * words, h->win + off, h->bits_host_dev + off * words, n, pl.H, pl.WW, h->copy_stream);
     else
         LG_HIP(h, hipMemcpyAsync(h->bits_host + off * words, h->bits + off * words, sizeof(unsigned long long) * n * words,
                                  hipMemcpyDeviceToHost, h->copy_stream));
     LG_HIP(h, hipMemcpyAsync(h->win_host + off, h->win + off, sizeof(LgWin) * n, hipMemcpyDeviceToHost, h->copy_stream));
-    LG_HIP(h, hipEventRecord(ev_copy, h->copy_stream));
+    LG_HIP(h, hipEventRecord(h->ev_copy, h->copy_stream));
+    h->export_pending = false;
     return LG_OK;
 }
 
@@ -545,6 +561,7 @@ void host_orient_frame(lg_ctx* h, const Plan& pl, int b) {
 int finish_orient(lg_ctx* h, const Plan& pl, int off, int n, bool* upload) {
     *upload = true;
     if (!h->orient) {
+        if (h->export_pending) { const int rc = enq_export(h, pl, 0, pl.B, nullptr); if (rc) return rc; }
         LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bit rows are on the host; the sweeps are running
         parallel_for(h, n, [=, &pl](int i) { host_orient_frame(h, pl, off + i); });
         return LG_OK;
@@ -555,6 +572,7 @@ int finish_orient(lg_ctx* h, const Plan& pl, int off, int n, bool* upload) {
         if (h->orient->h_status[off + i]) redo.push_back(off + i);
     *upload = !redo.empty();
     if (redo.empty()) return LG_OK;
+    if (h->export_pending) { const int rc = enq_export(h, pl, 0, pl.B, nullptr); if (rc) return rc; }
     LG_HIP(h, hipEventSynchronize(h->ev_copy));
     const int* rp = redo.data();
     parallel_for(h, (int)redo.size(), [=, &pl](int i) { host_orient_frame(h, pl, rp[i]); });
@@ -652,7 +670,7 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
             pl.maps[i] = h->ws_maps[i];
         }
     if (!pl.valid) pl.valid = h->ws_valid;
-    rc = enq_prep(h, pl, 0, B, s, h->ev_prep, h->ev_copy);
+    rc = enq_prep(h, pl, 0, B, s, h->ev_prep);
     if (rc) return rc;
     rc = enq_dt(h, pl, 0, B, s);
     if (rc) return rc;
@@ -971,6 +989,11 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                 lg_launch_gather(depth + off * px, mask + off * px, mp, n, H, W, K, h->cand_xy + (size_t)off * K * 2,
                                  h->cand_n + off, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, sM);
             }
+            if (h->export_pending) {   // bit rows -> host beside the MFMA-bound CNN (beside the gather it doubled the gather's time)
+                LG_HIP(h, hipEventRecord(h->ev_export, sM));
+                const int r3 = enq_export(h, pl, 0, B, h->ev_export);
+                if (r3) return r3;
+            }
             std::string err;
             hipStream_t sC = sM;
             if (h->s_cnn) {   // experiment: the CNN on its CU-masked stream, ordered after the gather and before the copy-back
@@ -999,9 +1022,13 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         hipEventRecord(tev[0], s);
     }
     // bit rows of the whole batch first (one short kernel) so the host never waits behind a distance sweep
-    rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep, h->ev_copy);
+    rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep);
     if (rc) return rc;
-    if (piped) LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
+    if (piped) {   // (experimental sub-batch pipeline: export right away, as before)
+        rc = enq_export(h, pl, 0, B, nullptr);
+        if (rc) return rc;
+        LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
+    }
     for (int k = 0; k < nsub; k++) {
         const int off = k * SB, n = std::min(SB, B - off);
         rc = enq_dt(h, pl, off, n, sD[k & 1]);
@@ -1033,6 +1060,11 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         }
         if (trace && !piped) hipEventRecord(tev[3], s);   // after top-k
         if (piped) LG_HIP(h, hipEventRecord(EV(k, 4), sT));
+        if (h->export_pending && !use_cnn) {   // bit rows -> host behind the top-k, not beside the sweeps (with the CNN: behind the gather)
+            LG_HIP(h, hipEventRecord(h->ev_export, sT));
+            rc = enq_export(h, pl, 0, B, h->ev_export);
+            if (rc) return rc;
+        }
         if (k >= 1) { rc = enq_G(k - 1); if (rc) return rc; }
     }
     rc = enq_G(nsub - 1);

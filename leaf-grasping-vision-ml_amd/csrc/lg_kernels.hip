@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
     const int t = threadIdx.x;
     const size_t fo = (size_t)frame * H * W;
     const int sup = 2 * md;
+    const float inv_w = __frcp_rn((float)W);
     for (int i = t; i < ntile; i += LG_TOPK_T) s_keys[i] = tilekeys[(size_t)frame * ntile + i];
     if (t == 0) s_best = 0;
     __syncthreads();
@@ -1300,7 +1301,11 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         const unsigned long long bk = s_best;
         if (bk == 0) break;  // every pixel is suppressed
         const int idx = (int)(uint32_t)(bk & 0xffffffffull);
-        const int px = idx % W, py = idx / W;
+        // idx < 2^24 (at most 8192 tiles of 1024 pixels): the float quotient is within 1 of idx / W
+        int py = (int)(((float)idx + 0.5f) * inv_w);
+        py -= (py * W > idx) ? 1 : 0;
+        py += ((py + 1) * W <= idx) ? 1 : 0;
+        const int px = idx - py * W;
         if (t == 0) {
             s_cx[r] = px; s_cy[r] = py;
             out_xy[((size_t)frame * k + r) * 2 + 0] = px;
@@ -1317,11 +1322,6 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
         for (int i = t; i < naff; i += LG_TOPK_T)   // any window size: a large min_distance touches > 1024 tiles
             s_keys[(ty_lo + i / ntx) * tiles_x + tx_lo + i % ntx] = 0;
         __syncthreads();
-        // 1024-pixel chunks, 2 per tile.  Loads of up to 12 chunks are issued together (one round trip to L2/HBM
-        // instead of one per chunk: each round of the greedy walk is a dependent chain, latency is everything).
-        constexpr int CPT = LG_TW * LG_TH / LG_TOPK_T;
-        const int chunks = naff * CPT;
-        constexpr int GRP = 12;
         // earlier picks whose suppression window reaches the affected tiles at all (usually the new pick and a neighbour or
         // two): the per-pixel test below walks these, not all r + 1 picks -- at the late rounds that test was most of the round
         unsigned long long rel = 0;
@@ -1330,26 +1330,87 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
             for (int q = 0; q <= r; q++)
                 if (s_cx[q] + sup >= xlo && s_cx[q] - sup <= xhi && s_cy[q] + sup >= ylo && s_cy[q] - sup <= yhi) rel |= 1ull << q;
         }
+        constexpr int TPT = LG_TOPK_T / 8;                 // threads per tile on the fast path: 8 tiles x 128 threads x 8 pixels
+        static_assert(LG_TW * LG_TH == 8 * TPT, "one tile = 128 threads x 8 pixels");
+        if (naff <= 8 && (W & 3) == 0) {
+            // The usual case (min_distance 10: a 41 x 41 window touches at most 2 x 4 tiles), kept short: the whole kernel runs on
+            // ONE CU per frame, every round is a dependent chain, and the general form below spent ~2500 instructions per wave and
+            // round on per-chunk index arithmetic (runtime divisions) -- 15 us of instruction issue per round, 0.3 ms per call at
+            // any batch size.  Thread t: tile t >> 7 of the window, row (t & 127) >> 3, eight consecutive pixels: two 16-byte score
+            // loads + one 8-byte validity load, all issued before anything is looked at.
+            const int ta = t >> 7, u = t & 127;
+            if (ta < naff) {
+                int ry = 0, rx = ta;
+                while (rx >= ntx) { rx -= ntx; ry++; }       // (ntx <= 8: a few wave-uniform iterations instead of a division)
+                const int tile = (ty_lo + ry) * tiles_x + tx_lo + rx;
+                const int y = (ty_lo + ry) * LG_TH + (u >> 3), x0 = (tx_lo + rx) * LG_TW + (u & 7) * 8;
+                unsigned long long best = 0;
+                if (y < H && x0 < W) {
+                    const size_t o = fo + (size_t)y * W + x0;
+                    const bool two = x0 + 4 < W;             // W % 4 == 0: groups of four pixels are inside or outside as a whole
+                    const float4 s0 = *reinterpret_cast<const float4*>(trad + o);
+                    const float4 s1 = two ? *reinterpret_cast<const float4*>(trad + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const uint32_t v0 = *reinterpret_cast<const uint32_t*>(valid + o);
+                    const uint32_t v1 = two ? *reinterpret_cast<const uint32_t*>(valid + o + 4) : 0u;
+                    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    // rows: which of the relevant picks reach this row at all (the column test is then per pixel)
+                    unsigned long long rowrel = 0;
+                    for (unsigned long long m = rel; m; m &= m - 1) {
+                        const int q = __builtin_ctzll(m);
+                        if (abs(y - s_cy[q]) <= sup) rowrel |= 1ull << q;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int x = x0 + j;
+                        const bool inside = j < 4 || two;
+                        const uint32_t vb = ((j < 4 ? v0 : v1) >> (8 * (j & 3))) & 0xffu;
+                        bool dead = false;
+                        for (unsigned long long m = rowrel; m; m &= m - 1) dead |= abs(x - s_cx[__builtin_ctzll(m)]) <= sup;
+                        if (inside && !dead) {
+                            const unsigned long long key = ((unsigned long long)lg_orderable(vb ? sc[j] : 0.0f) << 32) | (uint32_t)(y * W + x);
+                            best = key > best ? key : best;
+                        }
+                    }
+                }
+                best = lg_wave_max_u64(best);
+                if ((t & 63) == 0 && best) atomicMax(&s_keys[tile], best);
+            }
+            __syncthreads();
+            continue;
+        }
+        // General form (any window size, any width): 1024-pixel chunks, one per tile; the loads of up to 12 chunks are issued
+        // together (one round trip to L2 / HBM instead of one per chunk).
+        constexpr int CPT = LG_TW * LG_TH / LG_TOPK_T;
+        const int chunks = naff * CPT;
+        constexpr int GRP = 12;
         for (int cb = 0; cb < chunks; cb += GRP) {
             float sc_[GRP];
             int idx_[GRP], tile_[GRP], x_[GRP], y_[GRP];
+            unsigned off_[GRP];
+            // addresses first, then every load of the group back to back with nothing conditional on a loaded value in between
+            // (written as `valid[o] ? trad[o] : 0` per chunk, hipcc issued byte load -> wait -> branch -> float load -> wait for
+            // each chunk)
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
-                const int c = cb + g;
-                sc_[g] = 0.0f; idx_[g] = -1; tile_[g] = 0; x_[g] = 0; y_[g] = 0;
-                if (c < chunks) {
-                    const int ta = c / CPT;
-                    const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
-                    const int li = (c % CPT) * LG_TOPK_T + t;
-                    const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
-                    tile_[g] = tile; x_[g] = x; y_[g] = y;
-                    if (x < W && y < H) {
-                        const size_t o = fo + (size_t)y * W + x;
-                        idx_[g] = y * W + x;
-                        sc_[g] = valid[o] ? trad[o] : 0.0f;
-                    }
-                }
+                const int c = min(cb + g, chunks - 1);
+                const int ta = c / CPT;
+                const int tile = (ty_lo + ta / ntx) * tiles_x + tx_lo + ta % ntx;
+                const int li = (c % CPT) * LG_TOPK_T + t;
+                const int x = (tile % tiles_x) * LG_TW + (li % LG_TW), y = (tile / tiles_x) * LG_TH + (li / LG_TW);
+                const bool inb = x < W && y < H;
+                tile_[g] = tile; x_[g] = x; y_[g] = y;
+                idx_[g] = inb ? y * W + x : -1;
+                off_[g] = inb ? (unsigned)(y * W + x) : 0u;   // (outside the image: pixel 0 of the frame, loaded and ignored)
             }
+            uint8_t vv_[GRP];
+            float tt_[GRP];
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+                vv_[g] = __builtin_nontemporal_load(valid + fo + off_[g]);
+                tt_[g] = __builtin_nontemporal_load(trad + fo + off_[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < GRP; g++) sc_[g] = (idx_[g] >= 0 && vv_[g]) ? tt_[g] : 0.0f;
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
                 if (cb + g < chunks) {   // uniform across the workgroup
