@@ -434,16 +434,19 @@ def main():
             achieved = launch_bytes / (kern["final"]["avg_ms"] * 1e-3) / 1e9
             # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
             # + WRITE_SIZE), recorded per pixel in profiles/ by tools/pmc_final.sh; scaled to this launch.
-            traffic = None
-            try:
-                with open(os.path.join(REPO, "profiles", "r02_pmc_counters.json")) as fpmc:
-                    traffic = round(json.load(fpmc)["lg_final_kernel_summary"]["traffic_bytes_per_px"] * px)
-            except Exception:  # noqa: BLE001
-                traffic = None
+            traffic, traffic_file = None, None
+            for cand in ("r03_pmc_counters.json", "r02_pmc_counters.json"):
+                try:
+                    with open(os.path.join(REPO, "profiles", cand)) as fpmc:
+                        traffic = round(json.load(fpmc)["lg_final_kernel_summary"]["traffic_bytes_per_px"] * px)
+                    traffic_file = cand
+                    break
+                except Exception:  # noqa: BLE001
+                    traffic = None
             out["roofline"] = {"kernel": "lg_final_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic,
-                               "traffic_source": "profiles/r02_pmc_counters.json: rocprofv3 --pmc passes of a 32-frame 1080p launch of this "
+                               "traffic_source": f"profiles/{traffic_file}: rocprofv3 --pmc passes of a 32-frame 1080p launch of this "
                                                  "kernel (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_final.sh), bytes per pixel x this "
                                                  "launch's pixels -- NOT counted during this run",
                                "bytes_per_launch": round(launch_bytes),
@@ -516,11 +519,13 @@ def main():
                 except (OSError, ValueError, IndexError):
                     pass
                 traffic_d = None
-                try:
-                    with open(os.path.join(REPO, "profiles", "r02_pmc_final_dense.json")) as fpmc:
-                        traffic_d = round(json.load(fpmc)["traffic_bytes_per_px"] * nd * H * W)
-                except Exception:  # noqa: BLE001
-                    traffic_d = None
+                for cand in ("r03_pmc_final_dense.json", "r02_pmc_final_dense.json"):
+                    try:
+                        with open(os.path.join(REPO, "profiles", cand)) as fpmc:
+                            traffic_d = round(json.load(fpmc)["traffic_bytes_per_px"] * nd * H * W)
+                        break
+                    except Exception:  # noqa: BLE001
+                        traffic_d = None
                 out["roofline_dense"] = {"kernel": "lg_final_kernel (every tile on the stencil path)", "bound": "hbm",
                                          "achieved": round(dach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": round(dach / HBM_PEAK_GBS, 4), "traffic": traffic_d,

@@ -266,7 +266,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                 sx += x;
                 sd += (double)dv[k];
                 const double dx = (double)x - (double)cx;
-                sr += sqrt(dx * dx + dy * dy + f2);
+                // f64 square root = f32 square root (1 ulp) + one Newton step in f64 (relative error ~1e-14; the correctly rounded
+                // v_sqrt_f64 sequence was the single most expensive thing in this kernel's inner loop)
+                const double v = dx * dx + dy * dy + f2;
+                const float r0 = __builtin_amdgcn_sqrtf((float)v);
+                const double rd = (double)r0;
+                sr += rd + (v - rd * rd) * (double)(0.5f * __frcp_rn(r0));
                 bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
                 *dst++ = ((unsigned long long)(unsigned)cur_slot << 32) | f2key(dv[k]);
             }
@@ -333,22 +338,34 @@ __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restri
         // One entry per lane and load (512 contiguous bytes per wave instruction).  The pixels of a run sit next to each other
         // in the list and the depths of a leaf share their high bytes, so neighbouring lanes mostly hit the SAME (slot, bin):
         // each maximal group of equal neighbours inside the wave becomes one LDS atomic of its first lane (ballot of the heads).
-        for (unsigned i0 = 0; i0 < n; i0 += 256) {
-            const unsigned i = i0 + threadIdx.x;
-            int idx = -1;
-            if (i < n) {
-                const unsigned long long e = comp[i];
-                const int slot = (int)(e >> 32) - g * LGL_GROUP;
-                const uint32_t key = (uint32_t)e;
-                if ((unsigned)slot < (unsigned)nsl && (key & himask) == (s_prefix[slot] & himask)) idx = slot * 256 + (int)((key >> shift) & 0xFFu);
+        // Four loads per thread in flight: with 64 KB of LDS per workgroup two workgroups (two waves per SIMD) share a CU, and one
+        // load -> wait -> count round per 256 entries left the pass bound by the list's load latency (0.33 ms for 0.34 GB; the
+        // successor pass reads the same list in 0.09 ms).
+        constexpr int UNR = 4;
+        for (unsigned i0 = 0; i0 < n; i0 += 256 * UNR) {
+            unsigned long long e_[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; k++) {
+                const unsigned i = i0 + k * 256 + threadIdx.x;
+                e_[k] = i < n ? __builtin_nontemporal_load(comp + i) : ~0ull;
             }
-            const int prev = __shfl_up(idx, 1, 64);
-            const bool head = lane == 0 || idx != prev;
-            const unsigned long long hm = __ballot(head);
-            if (head && idx >= 0) {
-                const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
-                const int len = later ? __builtin_ctzll(later) + 1 : 64 - lane;
-                atomicAdd(&s_h[idx], (uint32_t)len);
+#pragma unroll
+            for (int k = 0; k < UNR; k++) {
+                int idx = -1;
+                if (i0 + k * 256 + threadIdx.x < n) {
+                    const unsigned long long e = e_[k];
+                    const int slot = (int)(e >> 32) - g * LGL_GROUP;
+                    const uint32_t key = (uint32_t)e;
+                    if ((unsigned)slot < (unsigned)nsl && (key & himask) == (s_prefix[slot] & himask)) idx = slot * 256 + (int)((key >> shift) & 0xFFu);
+                }
+                const int prev = __shfl_up(idx, 1, 64);
+                const bool head = lane == 0 || idx != prev;
+                const unsigned long long hm = __ballot(head);
+                if (head && idx >= 0) {
+                    const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
+                    const int len = later ? __builtin_ctzll(later) + 1 : 64 - lane;
+                    atomicAdd(&s_h[idx], (uint32_t)len);
+                }
             }
         }
         __syncthreads();

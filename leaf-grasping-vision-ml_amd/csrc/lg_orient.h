@@ -15,6 +15,7 @@ struct LgOrientWs {
     int *roots = nullptr, *row_start = nullptr;
     short *rowL = nullptr, *rowR = nullptr;
     unsigned char* vflag = nullptr;
+    int* comp = nullptr;            // [B][4][cap] per-component interior pixel count and bounding box (candidate test)
     double* out = nullptr;          // [B][5] theta, long side, short side, centre x, centre y
     int* status = nullptr;          // [B] 0 done on the device, 1 frame needs the host analysis
     double* h_out = nullptr;        // pinned copies

@@ -132,6 +132,7 @@ struct FrameScratch {
     short* rowL;       // leftmost / rightmost pixel of the chosen component per band row (-1: none)
     short* rowR;
     unsigned char* vflag;   // [2][hy] strict hull vertex on the left / right chain
+    int* comp;              // [4][cap] per component (indexed by its root run): interior pixels, min x, max x, last row
 };
 
 __device__ void write_none(LgFrameParams* fp, double* out, int* status, int b, int st) {
@@ -145,11 +146,11 @@ __device__ void write_none(LgFrameParams* fp, double* out, int* status, int b, i
 __global__ __launch_bounds__(OT) void lg_orient_kernel(const u64* __restrict__ bits, const LgWin* __restrict__ win, int H, int W,
                                                        int WW, int cap, uint32_t* run_x_, uint16_t* run_y_, int* roots_,
                                                        int* row_start_, short* rowL_, short* rowR_, unsigned char* vflag_,
-                                                       LgFrameParams* fp, double* out, int* status) {
+                                                       int* comp_, LgFrameParams* fp, double* out, int* status) {
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char s_dyn[];   // parent[cap] | L[n], R[n] shorts | hull x[OHULL], y[OHULL] doubles
     __shared__ int s_scan[OT];
-    __shared__ int s_nroots, s_ybot, s_rank;
+    __shared__ int s_nroots, s_ybot, s_rank, s_lb, s_ncand, s_cand;
     __shared__ u64 s_key, s_p0;
     const int b = blockIdx.x, tid = threadIdx.x;
     const LgWin w = win[b];
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(OT) void lg_orient_kernel(const u64* __restrict__ b
     fs.run_x = run_x_ + (size_t)b * cap; fs.run_y = run_y_ + (size_t)b * cap; fs.roots = roots_ + (size_t)b * cap;
     fs.row_start = row_start_ + (size_t)b * (H + 1); fs.rowL = rowL_ + (size_t)b * H; fs.rowR = rowR_ + (size_t)b * H;
     fs.vflag = vflag_ + (size_t)b * 2 * H;
+    fs.comp = comp_ + (size_t)b * 4 * cap;
     Band bd;
     bd.rows = bits + ((size_t)b * H + w.by0) * WW; bd.hy = hyb; bd.W = W; bd.WW = WW; bd.w0 = w.bx0 >> 6; bd.w1 = w.bx1 >> 6;
-    if (tid == 0) { s_nroots = 0; s_ybot = 0; s_key = 0; s_p0 = ~0ull; s_rank = 0x7fffffff; }
+    if (tid == 0) { s_nroots = 0; s_ybot = 0; s_key = 0; s_p0 = ~0ull; s_rank = 0x7fffffff; s_lb = 0; s_ncand = 0; s_cand = 0; }
     // ---- A: runs.  Thread t owns the rows [r0, r1)
     const int chunk = (hyb + OT - 1) / OT, r0 = min(tid * chunk, hyb), r1 = min(r0 + chunk, hyb);
     int sum = 0;
@@ -239,7 +241,10 @@ __global__ __launch_bounds__(OT) void lg_orient_kernel(const u64* __restrict__ b
     __syncthreads();
     for (int i = tid; i < R; i += OT) {
         const int root = uf_find(parent, i);
-        if (root == i) fs.roots[atomicAdd(&s_nroots, 1)] = i;
+        if (root == i) {
+            fs.roots[atomicAdd(&s_nroots, 1)] = i;
+            fs.comp[i] = 0; fs.comp[cap + i] = 0x7fffffff; fs.comp[2 * cap + i] = -1; fs.comp[3 * cap + i] = -1;
+        }
     }
     __syncthreads();
     for (int i = tid; i < R; i += OT) parent[i] = uf_find(parent, i);   // (a root stays a root: concurrent reads still end there)
@@ -250,10 +255,54 @@ __global__ __launch_bounds__(OT) void lg_orient_kernel(const u64* __restrict__ b
     if (nroots == 1) {
         best = fs.roots[0];
     } else {
+        // Which components can hold the largest outer contour at all?  Following a border is serial (one lane per component, a
+        // dependent chain of bit-row loads per step: ~1 us per border pixel), so a leaf with a few specks beside it would cost a
+        // few thousand steps for a decision that is obvious.  Two bounds on a component's contour area A (the area of the polygon
+        // through the centres of its outer border pixels): A >= the number of its pixels whose whole 3 x 3 neighbourhood is set
+        // (their unit squares are disjoint and lie inside that polygon) and A <= (width - 1) (height - 1) of its bounding box.
+        // A component whose upper bound is below the best lower bound is out -- it cannot even tie.  One survivor: no border is
+        // followed at all.
+        for (int i = tid; i < R; i += OT) {
+            const int root = parent[i], r = fs.run_y[i];
+            const uint32_t xi = fs.run_x[i];
+            const int x0 = (int)(xi & 0xffffu), x1 = (int)(xi >> 16);
+            int inner = 0;
+            if (x1 - x0 >= 2 && r > 0 && r < hyb - 1) {
+                for (int q = x0 >> 6; q <= (x1 >> 6); q++) {
+                    const u64 f0 = band_word(bd, r - 1, q - 1) & band_word(bd, r, q - 1) & band_word(bd, r + 1, q - 1);
+                    const u64 f1 = band_word(bd, r - 1, q) & band_word(bd, r, q) & band_word(bd, r + 1, q);
+                    const u64 f2 = band_word(bd, r - 1, q + 1) & band_word(bd, r, q + 1) & band_word(bd, r + 1, q + 1);
+                    u64 in3 = f1 & ((f1 << 1) | (f0 >> 63)) & ((f1 >> 1) | (f2 << 63));
+                    const int lo = max(x0 - q * 64, 0), hi = min(x1 - q * 64, 63);
+                    in3 &= (~0ull << lo) & (~0ull >> (63 - hi));
+                    inner += __popcll(in3);
+                }
+            }
+            if (inner) atomicAdd(&fs.comp[root], inner);
+            atomicMin(&fs.comp[cap + root], x0);
+            atomicMax(&fs.comp[2 * cap + root], x1);
+            atomicMax(&fs.comp[3 * cap + root], r);
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int k = tid; k < nroots; k += OT) atomicMax(&s_lb, fs.comp[fs.roots[k]]);
+        __syncthreads();
+        const long long lb2 = 2ll * s_lb;
         for (int k = tid; k < nroots; k += OT) {
             const int root = fs.roots[k];
-            const long long a2 = trace_area2(bd, (int)(fs.run_x[root] & 0xffffu), (int)fs.run_y[root]);
-            atomicMax(&s_key, ((u64)a2 << 20) | (u64)(0xfffff - root));   // a2 <= 2 H W < 2^29; equal areas: first in raster order
+            const long long ub2 = 2ll * (fs.comp[2 * cap + root] - fs.comp[cap + root]) * (fs.comp[3 * cap + root] - (int)fs.run_y[root]);
+            if (ub2 >= lb2) { atomicAdd(&s_ncand, 1); atomicMax(&s_cand, root); } else fs.roots[k] = -1;
+        }
+        __syncthreads();
+        if (s_ncand == 1) {
+            if (tid == 0) s_key = (u64)(0xfffff - s_cand);
+        } else {
+            for (int k = tid; k < nroots; k += OT) {
+                const int root = fs.roots[k];
+                if (root < 0) continue;
+                const long long a2 = trace_area2(bd, (int)(fs.run_x[root] & 0xffffu), (int)fs.run_y[root]);
+                atomicMax(&s_key, ((u64)a2 << 20) | (u64)(0xfffff - root));   // a2 <= 2 H W < 2^29; equal areas: first in raster order
+            }
         }
         __syncthreads();
         best = 0xfffff - (int)(s_key & 0xfffffull);
@@ -407,7 +456,7 @@ hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T));
 void lg_orient_free(LgOrientWs*& w) {
     if (!w) return;
     hipFree(w->run_x); hipFree(w->run_y); hipFree(w->roots); hipFree(w->row_start); hipFree(w->rowL); hipFree(w->rowR);
-    hipFree(w->vflag); hipFree(w->out); hipFree(w->status);
+    hipFree(w->vflag); hipFree(w->comp); hipFree(w->out); hipFree(w->status);
     if (w->h_out) hipHostFree(w->h_out);
     if (w->h_status) hipHostFree(w->h_status);
     delete w;
@@ -427,7 +476,7 @@ int lg_orient_ensure(LgOrientWs*& w, int B, int H, std::string* err) {
     auto A = [&](hipError_t r) { if (rc == hipSuccess) rc = r; };
     A(dalloc(&w->run_x, nb * w->cap)); A(dalloc(&w->run_y, nb * w->cap)); A(dalloc(&w->roots, nb * w->cap));
     A(dalloc(&w->row_start, nb * (H + 1))); A(dalloc(&w->rowL, nb * H)); A(dalloc(&w->rowR, nb * H));
-    A(dalloc(&w->vflag, nb * 2 * H)); A(dalloc(&w->out, nb * 5)); A(dalloc(&w->status, nb));
+    A(dalloc(&w->vflag, nb * 2 * H)); A(dalloc(&w->comp, nb * 4 * w->cap)); A(dalloc(&w->out, nb * 5)); A(dalloc(&w->status, nb));
     A(hipHostMalloc((void**)&w->h_out, sizeof(double) * 5 * nb));
     A(hipHostMalloc((void**)&w->h_status, sizeof(int) * nb));
     if (rc != hipSuccess) {
@@ -453,5 +502,5 @@ void lg_launch_orient(LgOrientWs* w, const unsigned long long* bits, const LgWin
     const size_t o = (size_t)off;
     hipLaunchKernelGGL(lg_orient_kernel, dim3(n), dim3(OT), w->lds, s, bits, win, H, W, WW, w->cap, w->run_x + o * w->cap,
                        w->run_y + o * w->cap, w->roots + o * w->cap, w->row_start + o * (H + 1), w->rowL + o * H, w->rowR + o * H,
-                       w->vflag + o * 2 * H, fp, w->out + 5 * o, w->status + o);
+                       w->vflag + o * 2 * H, w->comp + o * 4 * w->cap, fp, w->out + 5 * o, w->status + o);
 }

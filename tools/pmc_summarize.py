@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Folds the rocprofv3 --pmc passes of tools/pmc_final.sh (gpurun_out/pmc/{sq,fetch,write,tcc}) into
-profiles/r02_pmc_counters.json: per-kernel counter averages per dispatch and the HBM traffic of lg_final_kernel
+profiles/<out> (default r03_pmc_counters.json): per-kernel counter averages per dispatch and the HBM traffic of lg_final_kernel
 (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is, both KiB).
-usage: python tools/pmc_summarize.py <batch> <H> <W> <algorithmic bytes per px of lg_final_kernel for the benched masks>"""
+usage: python tools/pmc_summarize.py <batch> <H> <W> <algorithmic bytes per px of lg_final_kernel for the benched masks> [out.json]"""
 import collections
 import csv
 import glob
@@ -41,7 +41,7 @@ if fk and "FETCH_SIZE" in fk and "WRITE_SIZE" in fk:
         "dense_bytes_per_px": 37.25, "traffic_over_algorithmic": (rd + wr) / px / alg,
         "l2_hit_rate": fk["TCC_HIT_sum"] / (fk["TCC_HIT_sum"] + fk["TCC_MISS_sum"]) if "TCC_HIT_sum" in fk else None,
     }
-json.dump(out, open(os.path.join(REPO, "profiles", "r02_pmc_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(REPO, "profiles", sys.argv[5] if len(sys.argv) > 5 else "r03_pmc_counters.json"), "w"), indent=1)
 print(json.dumps(out.get("lg_final_kernel_summary"), indent=1))
 for k, v in out["kernels"].items():
     print(k[:50], {c: round(x) for c, x in v.items() if c in ("FETCH_SIZE", "WRITE_SIZE")})
