@@ -106,6 +106,8 @@ int main(int argc, char** argv) {
         {"tiled    256x4  same mix", 37.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<256, 4, true>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"tiled    64x16  no byte plane", 36.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<64, 16, true, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"writes   64x16  7W4 + 1W1", 29.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<64, 16, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
+        {"writes   256x4  7W4 + 1W1", 29.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<256, 4, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
+        {"writes   128x8  7W4 + 1W1", 29.0, time_ms([&] { hipLaunchKernelGGL((k_tiled<128, 8, false>), dim3(grid), dim3(256), 0, 0, P, B, H, W); }, reps)},
         {"copy     2R + 1W4", 12.0, time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, P, npx); }, reps)},
     };
     printf("frames=%d (%d x %d), %d resident workgroups of 256 threads, median of %d launches\n", B, H, W, grid, reps);
