@@ -39,6 +39,8 @@ struct LgGaussTaps { float k[LG_MAX_GAUSS]; };   // 1-D factor of ImageProcessor
 struct LgWin {
     int wx0, nw, wy0, wy1;   // window: first column, active waves (64*E columns each), row range
     int bx0, bx1, by0, by1;  // bounding box of the mask (bx1 < bx0: empty mask -> window = whole frame)
+    int skip_out;            // 1: max d_out cannot lie inside the window (see lg_bbox_kernel): the d_out sweeps of this frame are skipped
+    int pad_[3];
 };
 
 struct LgFrameParams {  // per frame: leaf orientation, written by lg_orient_kernel (or by the host analysis for frames it hands back)

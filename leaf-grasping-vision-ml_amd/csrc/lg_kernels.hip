@@ -258,6 +258,10 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
 }
 
 // ============================================================================ sweep window (mask bounding box)
+__device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form norm of the (1, 1.4, 2.1969) chamfer mask
+    const uint32_t a = (uint32_t)max(dx, dy), b = (uint32_t)min(dx, dy);
+    return 2u * b <= a ? (a - 2u * b) * LG_A5 + b * LG_C5 : (a - b) * LG_C5 + (2u * b - a) * LG_B5;
+}
 // One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).
 __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
                                                       int H, int W, int WW, int wc, int nw_max) {
@@ -290,12 +294,25 @@ __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* 
         if (w.bx1 < 0) {   // empty mask: no window (d_out has no source: the closed form of the whole frame applies)
             w.bx0 = 0; w.bx1 = -1; w.by0 = 0; w.by1 = -1;
             w.wx0 = 0; w.nw = nw_max; w.wy0 = 0; w.wy1 = H;
+            w.skip_out = 0;
         } else {
             w.wx0 = (w.bx0 / LG_TW) * LG_TW;
             w.nw = (w.bx1 + 1 - w.wx0 + wc - 1) / wc;
             w.wy0 = (w.by0 / LG_TH) * LG_TH;
             w.wy1 = min(H, ((w.by1 + 1 + LG_TH - 1) / LG_TH) * LG_TH);
+            // Only max d_out is consumed (grasp_point_selector.py:531-533).  Inside the window d_out(p) <= N(p - q) for any leaf
+            // pixel q, and both lie in the window: <= N(window width - 1, window height - 1).  At a frame corner every leaf pixel is
+            // at least the corner's gap to the bounding box away in x and in y: d_out(corner) >= N(gap_x, gap_y) (N is monotone in
+            // both).  When the best corner bound exceeds the window bound, the maximum is the frame-border maximum that
+            // lg_dout_border_kernel computes exactly, and the two d_out sweeps of this frame have nothing to add: they are skipped
+            // (the usual case: a leaf is a few hundred pixels across, the frame's far corner a thousand away).
+            const int ww = min(W, w.wx0 + w.nw * wc) - w.wx0, wh = w.wy1 - w.wy0;
+            const uint32_t ub_in = lg_norm5(ww - 1, wh - 1);
+            const int gx = max(w.bx0, W - 1 - w.bx1), gy = max(w.by0, H - 1 - w.by1);
+            // (strictly larger: the corner that achieves it then lies outside the window, on a border line lg_dout_border_kernel walks)
+            w.skip_out = lg_norm5(gx, gy) > ub_in ? 1 : 0;
         }
+        w.pad_[0] = w.pad_[1] = w.pad_[2] = 0;
         wins[frame] = w;
     }
 }
@@ -312,10 +329,6 @@ void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, in
 // the maximum over the outside region sits on the frame border, and beyond the bounding box's span at a frame corner.
 // grid (4, B): side 0 = top row, 1 = bottom row, 2 = left column, 3 = right column.  For a candidate on the top row
 // only the topmost leaf pixel of each column can be the nearest one of that column (same dx, smallest dy), etc.
-__device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form norm of the (1, 1.4, 2.1969) chamfer mask
-    const uint32_t a = (uint32_t)max(dx, dy), b = (uint32_t)min(dx, dy);
-    return 2u * b <= a ? (a - 2u * b) * LG_A5 + b * LG_C5 : (a - b) * LG_C5 + (2u * b - a) * LG_B5;
-}
 __global__ __launch_bounds__(256) void lg_dout_border_kernel(const unsigned long long* __restrict__ bits,
                                                              const LgWin* __restrict__ wins, uint32_t* __restrict__ maxfix,
                                                              int H, int W, int WW, int wc) {
@@ -420,6 +433,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     const LgWin win = wins[frame];
     const int nwa = win.nw;
     if (wave >= nwa) return;
+    if (which == 1 && win.skip_out) return;   // max d_out lies on the frame border (lg_bbox_kernel): whole workgroup, before any barrier
     const int wx0 = win.wx0, wxe = wx0 + nwa * WC;   // window columns [wx0, wxe); columns >= W are outside the image
     const int wy0 = win.wy0, HW = win.wy1 - win.wy0; // window rows
     const size_t fo = (size_t)frame * H * W;
