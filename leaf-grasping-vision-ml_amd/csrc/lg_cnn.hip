@@ -46,7 +46,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
 #endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results),
                       //   256 epilogue arithmetic without its stores, 512 stores into one small region,
-                      //   2048 / 4096 no stores from the staging / the transform waves
+                      //   2048 / 4096 no stores from the staging / the transform waves, 8192 half the fragment reads (B operand stale)
 
 namespace {
 
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         constexpr int SCNT = 4 * (POOL ? 2 : 4);                // plane-store instructions of one epilogue that are always issued
         int q = 0;                                              // chunk counter over all items (stage parity)
         f32x4 fa[3] = {}, fb[3] = {};
-#define LG_FRAG_AT(PG, AP, BP) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], AP); lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], BP); }
+#define LG_FRAG_AT(PG, AP, BP) if (!(LG_W4_EXP & 16)) { lg_lds_read16<(PG) * 1024>(fa[(PG) % 3], AP); if (!(LG_W4_EXP & 8192)) lg_lds_read16<(PG) * 1024>(fb[(PG) % 3], BP); }
         {
             const unsigned ap0 = (unsigned)(size_t)a_rd, bp0 = (unsigned)(size_t)b_rd;
             LG_FRAG_AT(0, ap0, bp0); LG_FRAG_AT(1, ap0, bp0); LG_FRAG_AT(2, ap0, bp0);
