@@ -34,8 +34,9 @@ for case in range(n_cases):
         mask = (labels == 2) | (labels == 3)
     mask = mask.astype(np.uint8)
     sel.set_camera_params(P)
-    maps, valid, theta = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda())
-    ref = O.RefGraspPointSelector()
+    gs = int(rng.choice([1, 3, 7])) if case % 3 == 1 else 5      # the caller's ImageProcessor decides the smoothing (round 3)
+    maps, valid, theta = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda(), L.ImageProcessor(H, W, 21, gs))
+    ref = O.RefGraspPointSelector(gaussian_size=gs)
     ref.set_camera_params(P)
     sc = ref._calculate_all_scores(mask, depth)
     msgs = []
@@ -52,12 +53,14 @@ for case in range(n_cases):
                 msgs.append(f"{k} maxabs {np.max(np.abs(g - v)):.3g}")
         if not np.array_equal(valid.cpu().numpy().astype(bool), ref._get_valid_regions(mask, sc)):
             msgs.append("valid")
-        cg = sel._get_candidate_points(maps["traditional_score"], valid, 20, 10)
-        co = ref._get_candidate_points(maps["traditional_score"].cpu().numpy(), valid.cpu().numpy().astype(bool), 20, 10)
-        if cg != co:
-            msgs.append("candidates(on the GPU planes)")
+        # top-k / spacing combinations: the usual window takes the kernel's short path, the others its general form
+        for kk, md in ((20, 10), ([5, 64, 20, 33][case % 4], [0, 3, 25, 40, 17][case % 5])):
+            cg = sel._get_candidate_points(maps["traditional_score"], valid, kk, md)
+            co = ref._get_candidate_points(maps["traditional_score"].cpu().numpy(), valid.cpu().numpy().astype(bool), kk, md)
+            if cg != co:
+                msgs.append(f"candidates(on the GPU planes, k={kk}, min_distance={md})")
     if msgs:
         bad += 1
-        print(f"case {case}: H={H} W={W} kind={kind}: " + "; ".join(msgs))
+        print(f"case {case}: H={H} W={W} kind={kind} gaussian={gs}: " + "; ".join(msgs))
 print(f"{n_cases - bad}/{n_cases} cases clean")
 sys.exit(1 if bad else 0)
