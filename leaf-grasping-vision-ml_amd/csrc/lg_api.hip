@@ -23,7 +23,7 @@
 #include "lg_orient.h"
 #include "lg_pool.h"
 
-#define LG_VERSION_STR "leafgrasp-gfx950 0.1"
+#define LG_VERSION_STR "leafgrasp-gfx950 0.3"
 
 struct LgProfSlot {
     std::string name;
