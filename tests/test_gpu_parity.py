@@ -509,6 +509,18 @@ def test_smooth_depth_through_the_library(L, golden, golden3):
         np.testing.assert_allclose(got, O.smooth_depth(d, size), rtol=2e-6, atol=1e-7)
     with pytest.raises(L.LgError):   # torch: reflect padding must be smaller than the input
         L.ImageProcessor(8, 8, 21, 15).smooth_depth(torch.zeros(7, 7), "cuda:0")
+    # the C entry point takes B frames per call: three frames at once equal the three single calls
+    import ctypes as C
+    from leafgrasp_amd import _lib
+    from leafgrasp_amd.image_processor import _handle
+    x = torch.from_numpy(rng.random((3, 45, 70)).astype(np.float32)).cuda()
+    out = torch.empty_like(x)
+    rc = _lib.lib.lg_smooth_depth(_handle(0), x.data_ptr(), 3, 45, 70, 5, out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    ip5 = L.ImageProcessor(45, 70, 21, 5)
+    for b in range(3):
+        np.testing.assert_array_equal(out[b].cpu().numpy(), ip5.smooth_depth(x[b], "cuda:0").cpu().numpy())
+    assert _lib.lib.lg_smooth_depth(_handle(0), x.data_ptr(), 3, 45, 70, 16, out.data_ptr(), None) == _lib.LG_ERR_UNSUPPORTED
 
 
 def test_flatness_follows_the_callers_image_processor(L, sel, golden, golden3):
