@@ -71,7 +71,8 @@ Respond with only a decimal number between 0.0 and 1.0.
 
     def _evaluate_single_candidate(self, image, prompt: str) -> float:  # :79-101
         try:
-            inputs = self.processor(prompt, image, return_tensors="pt").to(self.device)
+            # (by keyword: the reference's positional (prompt, image) is the transformers 4.3x order; 5.x takes (images, text))
+            inputs = self.processor(text=prompt, images=image, return_tensors="pt").to(self.device)
             with torch.no_grad():
                 output = self.model.generate(**inputs, max_new_tokens=10, do_sample=False, temperature=0.1)  # :85-90
             response = self.processor.decode(output[0], skip_special_tokens=True).split("assistant")[-1].strip()

@@ -16,7 +16,10 @@ class ScriptedProcessor:
     def __init__(self, script):
         self.script, self.prompts, self.n = script, [], 0
 
-    def __call__(self, prompt, image, return_tensors="pt"):
+    def __call__(self, *args, text=None, images=None, return_tensors="pt"):
+        # the reference calls processor(prompt, image, ...) positionally (the transformers 4.3x signature); this repo's scorer
+        # passes text= / images= by keyword, which every transformers version accepts
+        prompt = args[0] if args else text
         self.prompts.append(prompt)
         i = self.n
         self.n += 1

@@ -480,6 +480,39 @@ def test_hybrid_grasp_selector_with_the_llava_scorer_on_a_scripted_model(L):
     assert winners[1] == cands[0]["leaf_id"]          # constant 0.5 scores -> the geometric ranking decides
 
 
+def test_hybrid_grasp_selector_with_stock_llava_classes_in_bf16_on_the_gpu(L, tmp_path):
+    """BASELINE config 5 with everything real except the weights' values: the stock transformers LlavaNext classes, loaded from a
+    local tiny random checkpoint (tests/tiny_llava.py) in bf16 on the MI355X, score the candidates inside HybridGraspSelector;
+    the decision equals the same composition spelled out, the grasp point equals the oracle's for the winning leaf."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from leafgrasp_amd.vla_scorer import LLaVAScorer
+    from test_host_logic import _tiny_llava_expected
+    from tiny_llava import build_tiny_llava
+    path = build_tiny_llava(str(tmp_path / "tiny_llava"))
+    scorer = LLaVAScorer(device="cuda:0", model_path=path)               # bf16 by default, as config 5 names it
+    assert scorer.model is not None and next(scorer.model.parameters()).dtype == torch.bfloat16
+    assert next(scorer.model.parameters()).is_cuda
+    H, W = 720, 1280
+    labels, depth, P = O.synthetic_scene(H, W, 2)
+    hg = L.HybridGraspSelector("cuda:0", vla_scorer=scorer, load_model=False)
+    hg.set_camera_params(P)
+    dt = torch.from_numpy(depth).cuda()
+    cands = hg.generate_candidates(torch.from_numpy(labels).cuda(), dt)
+    img = np.random.default_rng(1).integers(0, 255, (60, 80, 3), dtype=np.uint8)
+    res = hg.select_grasp_point(img, cands, dt)
+    vla, _ = _tiny_llava_expected(scorer, img, cands, "Select the best leaf for grasping")
+    geo = [c["geometric_score"] for c in cands]
+    conf = L.ConfidenceManager().calculate_confidence(vla, geo)
+    exp_win = L.HybridSelector("cpu").select_best_candidate(cands, geo, vla, conf)
+    assert hg.last_selection["leaf_id"] == exp_win["leaf_id"]
+    rg = O.RefGraspPointSelector()
+    rg.set_camera_params(P)
+    exp = rg.select_grasp_point((labels == exp_win["leaf_id"]).astype(np.uint8), depth)
+    assert res[0] == exp[0]
+    np.testing.assert_allclose(res[1], exp[1], rtol=1e-5)
+
+
 def test_leaf_workspace_survives_a_change_of_aspect(L):
     """the leaf stage's bit rows are H x ceil(W / 64) words -- 480 x 640 needs 4800 per frame, 640 x 480 needs
     5120 at the same pixel count.  One handle, both shapes, either order: statistics and selection equal the oracle."""

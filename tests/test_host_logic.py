@@ -206,6 +206,48 @@ def test_llava_scorer_live_path_vs_reference_with_scripted_model():
     assert s.evaluate_candidates(image, cands[:3], instruction) == g["llava_eval_no_model"].tolist()
 
 
+def _tiny_llava_expected(scorer, image, cands, instruction):
+    """evaluate_candidates spelled out with the scorer's own processor / model: what llava_processor.py:33-112 computes."""
+    from PIL import Image
+    pil = Image.fromarray(np.ascontiguousarray(image[..., ::-1]))
+    raw, texts = [], []
+    for c in cands:
+        prompt = scorer._create_evaluation_prompt(c, instruction)
+        inputs = scorer.processor(text=prompt, images=pil, return_tensors="pt").to(scorer.device)
+        with torch.no_grad():
+            out = scorer.model.generate(**inputs, max_new_tokens=10, do_sample=False)
+        assert out.shape[1] <= inputs["input_ids"].shape[1] + 10
+        text = scorer.processor.decode(out[0], skip_special_tokens=True).split("assistant")[-1].strip()
+        texts.append(text)
+        try:
+            raw.append(float(np.clip(float(text), 0.0, 1.0)))
+        except ValueError:
+            raw.append(0.5)
+    a = np.array(raw)
+    return ([0.5] * len(a) if a.std() < 1e-6 else ((a - a.min()) / (a.max() - a.min())).tolist()), texts
+
+
+def test_llava_scorer_with_stock_transformers_classes_on_a_tiny_random_checkpoint(tmp_path):
+    """The path BASELINE config 5 takes when weights exist, with the stock LlavaNextProcessor / LlavaNextForConditionalGeneration
+    loaded from a LOCAL directory (tests/tiny_llava.py: 2-layer towers, random weights; the 7B checkpoint exists nowhere in this
+    pipeline): image tokens are expanded, generate runs greedily for at most 10 tokens, the decoded tail is parsed or falls back
+    to 0.5, scores are min-max normalised.  Here on the CPU in fp32; tests/test_gpu_leaf_and_node.py runs it in bf16 on the GPU."""
+    from leafgrasp_amd.vla_scorer import LLaVAScorer
+    from tiny_llava import build_tiny_llava, sample_image
+    path = build_tiny_llava(str(tmp_path / "tiny_llava"))
+    s = LLaVAScorer(device="cpu", model_path=path, dtype=torch.float32)
+    assert s.model is not None and type(s.processor).__name__ == "LlavaNextProcessor"
+    cands = [{"x": 10.0 * i, "y": 5.0 * i, "geometric_score": 0.2 + 0.1 * i, "clutter_score": 0.3, "distance_score": 0.6} for i in range(3)]
+    img = sample_image()
+    got = s.evaluate_candidates(img, cands, "Select the best leaf for grasping")
+    exp, texts = _tiny_llava_expected(s, img, cands, "Select the best leaf for grasping")
+    assert got == pytest.approx(exp, abs=1e-12) and len(got) == 3 and all(0.0 <= v <= 1.0 for v in got)
+    assert all(isinstance(t, str) for t in texts)
+    # a missing / broken checkpoint directory is the reference's load failure: model None, 0.5 for everyone (:28-36)
+    s2 = LLaVAScorer(device="cpu", model_path=str(tmp_path / "nothing_here"))
+    assert s2.model is None and s2.evaluate_candidates(img, cands) == [0.5, 0.5, 0.5]
+
+
 def test_harness_csv_format():
     from leafgrasp_amd.node_harness import LeafGraspHarness
     assert LeafGraspHarness.format_result((3, 4), (0.1, 0.2, 0.3), (0.4, 0.5, 0.6)) == "3,4,0.1,0.2,0.3,0.4,0.5,0.6"
