@@ -58,8 +58,8 @@ struct lg_ctx {
     uint8_t* ws_valid = nullptr;
     int32_t *cand_xy = nullptr, *cand_n = nullptr;
     float *cand_info = nullptr, *patches = nullptr, *logits = nullptr;
-    int32_t *h_xy = nullptr, *h_n = nullptr;  // pinned
-    float *h_info = nullptr, *h_logits = nullptr;
+    lg_grasp_result* res_dev = nullptr;       // [B] result rows written by lg_finish_kernel
+    lg_grasp_result* res_host = nullptr;      // pinned copy
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
@@ -174,10 +174,11 @@ void free_ws(lg_ctx* h) {
     for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps_base[i]); h->ws_maps_base[i] = h->ws_maps[i] = nullptr; }
     F(h->ws_valid); F(h->cand_xy); F(h->cand_n); F(h->cand_info); F(h->patches); F(h->logits);
     auto HF = [](void* p) { if (p) hipHostFree(p); };
-    HF(h->fp_host); HF(h->bits_host); HF(h->win_host); HF(h->h_xy); HF(h->h_n); HF(h->h_info); HF(h->h_logits);
+    HF(h->fp_host); HF(h->bits_host); HF(h->win_host); HF(h->res_host);
+    F(h->res_dev);
     h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->win = nullptr; h->fp_dev = nullptr;
     h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
-    h->fp_host = nullptr; h->bits_host = nullptr; h->win_host = nullptr; h->bits_host_dev = nullptr; h->h_xy = h->h_n = nullptr; h->h_info = h->h_logits = nullptr;
+    h->fp_host = nullptr; h->bits_host = nullptr; h->win_host = nullptr; h->bits_host_dev = nullptr; h->res_dev = h->res_host = nullptr;
     h->capB = h->capH = h->capW = h->capK = 0;
 }
 
@@ -212,10 +213,8 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, dev_alloc(&h->patches, (size_t)nB * nK * lg_cnn_halo_patch_floats()));
     LG_HIP(h, hipMemset(h->patches, 0, (size_t)nB * nK * lg_cnn_halo_patch_floats() * sizeof(float)));
     LG_HIP(h, dev_alloc(&h->logits, (size_t)nB * nK));
-    LG_HIP(h, hipHostMalloc((void**)&h->h_xy, sizeof(int32_t) * nB * nK * 2));
-    LG_HIP(h, hipHostMalloc((void**)&h->h_n, sizeof(int32_t) * nB));
-    LG_HIP(h, hipHostMalloc((void**)&h->h_info, sizeof(float) * nB * nK * 2));
-    LG_HIP(h, hipHostMalloc((void**)&h->h_logits, sizeof(float) * nB * nK));
+    LG_HIP(h, dev_alloc(&h->res_dev, (size_t)nB));
+    LG_HIP(h, hipHostMalloc((void**)&h->res_host, sizeof(lg_grasp_result) * nB));
     if (!h->opt_host_orient && H <= 16384 && W <= 8192) {
         // no device-side scratch (allocation, or the LDS request on a part with less of it): the host contour analysis of
         // every frame is a complete path of its own -- scoring goes on, the reason stays readable in orient_note
@@ -989,11 +988,6 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                 lg_launch_gather(depth + off * px, mask + off * px, mp, n, H, W, K, h->cand_xy + (size_t)off * K * 2,
                                  h->cand_n + off, h->patches + (size_t)off * K * lg_cnn_halo_patch_floats(), true, sM);
             }
-            if (h->export_pending) {   // bit rows -> host beside the MFMA-bound CNN (beside the gather it doubled the gather's time)
-                LG_HIP(h, hipEventRecord(h->ev_export, sM));
-                const int r3 = enq_export(h, pl, 0, B, h->ev_export);
-                if (r3) return r3;
-            }
             std::string err;
             hipStream_t sC = sM;
             if (h->s_cnn) {   // experiment: the CNN on its CU-masked stream, ordered after the gather and before the copy-back
@@ -1024,11 +1018,7 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     // bit rows of the whole batch first (one short kernel) so the host never waits behind a distance sweep
     rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep);
     if (rc) return rc;
-    if (piped) {   // (experimental sub-batch pipeline: export right away, as before)
-        rc = enq_export(h, pl, 0, B, nullptr);
-        if (rc) return rc;
-        LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
-    }
+    if (piped) LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
     for (int k = 0; k < nsub; k++) {
         const int off = k * SB, n = std::min(SB, B - off);
         rc = enq_dt(h, pl, off, n, sD[k & 1]);
@@ -1060,11 +1050,6 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         }
         if (trace && !piped) hipEventRecord(tev[3], s);   // after top-k
         if (piped) LG_HIP(h, hipEventRecord(EV(k, 4), sT));
-        if (h->export_pending && !use_cnn) {   // bit rows -> host behind the top-k, not beside the sweeps (with the CNN: behind the gather)
-            LG_HIP(h, hipEventRecord(h->ev_export, sT));
-            rc = enq_export(h, pl, 0, B, h->ev_export);
-            if (rc) return rc;
-        }
         if (k >= 1) { rc = enq_G(k - 1); if (rc) return rc; }
     }
     rc = enq_G(nsub - 1);
@@ -1077,83 +1062,25 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
             LG_HIP(h, hipStreamSynchronize(q));
         }
     }
-    if (use_cnn) LG_HIP(h, hipMemcpyAsync(h->h_logits, h->logits, sizeof(float) * B * K, hipMemcpyDeviceToHost, s));
-    LG_HIP(h, hipMemcpyAsync(h->h_xy, h->cand_xy, sizeof(int32_t) * B * K * 2, hipMemcpyDeviceToHost, s));
-    LG_HIP(h, hipMemcpyAsync(h->h_n, h->cand_n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
-    LG_HIP(h, hipMemcpyAsync(h->h_info, h->cand_info, sizeof(float) * B * K * 2, hipMemcpyDeviceToHost, s));
+    // ---- the rest of select_grasp_point per frame -- rescoring, 3-D point, pre-grasp probes -- on the device (lg_finish_kernel);
+    //      one copy of B result rows comes back
+    {
+        LgFinishArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.cand_n = h->cand_n; fa.cand_xy = h->cand_xy; fa.cand_info = h->cand_info; fa.logits = h->logits;
+        fa.fp = h->fp_dev; fa.bits = h->bits; fa.out = h->res_dev;
+        fa.B = B; fa.H = H; fa.W = W; fa.WW = pl.WW; fa.K = K; fa.use_cnn = use_cnn ? 1 : 0; fa.mask_is_bool = P.mask_is_bool;
+        fa.cx = P.cx; fa.cy = P.cy; fa.f = P.f;
+        lg_make_se_spans(2 * P.pregrasp_clearance + 1, &fa.se);
+        ProfScope ps(h, "finish", s);
+        lg_launch_finish(fa, s);
+    }
+    LG_HIP(h, hipMemcpyAsync(h->res_host, h->res_dev, sizeof(lg_grasp_result) * B, hipMemcpyDeviceToHost, s));
     const double t_enq2 = now();
     LG_HIP(h, hipStreamSynchronize(s));
-    LG_HIP(h, hipEventSynchronize(h->ev_copy));   // bounding-box bit rows for the pre-grasp clearance test below
     const double t_sync = now();
     LG_HIP(h, hipGetLastError());
-    std::vector<float> theta(B);
-    for (int b = 0; b < B; b++) theta[b] = h->fp_host[b].theta;
-
-    const int WW = (W + 63) / 64;
-    LgSeSpans pre_se;
-    lg_make_se_spans(2 * P.pregrasp_clearance + 1, &pre_se);
-    const int32_t* all_xy = h->h_xy;
-    const int32_t* all_n = h->h_n;
-    const float* all_info = h->h_info;
-    const float* all_logits = h->h_logits;
-    const unsigned long long* all_bits = h->bits_host;
-    const LgWin* all_win = h->win_host;
-    const float* thp = theta.data();
-    parallel_for(h, B, [=, &P, &pre_se](int b) {
-        lg_grasp_result& R = results[b];
-        memset(&R, 0, sizeof(R));
-        R.theta = thp[b];
-        const int n = all_n[b];
-        R.n_candidates = n;
-        if (n <= 0) return;  // reference: "No valid candidate points found" -> (None, None, None)
-        const int32_t* xy = all_xy + (size_t)b * K * 2;
-        const float* info = all_info + (size_t)b * K * 2;
-        int best = 0;
-        double best_score = info[0];  // candidate 0's traditional score (grasp_point_selector.py:205-206)
-        if (use_cnn && n > 1) {
-            for (int i = 0; i < n; i++) {
-                const int x = xy[2 * i], y = xy[2 * i + 1];
-                if (P.mask_is_bool && (x < 16 || y < 16 || x + 16 > W || y + 16 > H)) continue;
-                const double logit = all_logits[(size_t)b * K + i];
-                const double sg = 1.0 / (1.0 + exp(-logit));
-                const double ml = tanh(sg * 3.0) * 0.5 + 0.5;               // :133-136
-                const double conf = 1.0 - fabs(ml - 0.5) * 2.0;              // :222
-                const double wml = std::min(0.3, conf * 0.6);                // :223
-                const double comb = (1.0 - wml) * (double)info[2 * i] + wml * ml;  // :226
-                if (comb > best_score) { best_score = comb; best = i; R.ml_used = 1; }
-            }
-        }
-        R.found = 1;
-        R.x = xy[2 * best]; R.y = xy[2 * best + 1];
-        R.best_score = (float)best_score;
-        // get_3d_grasp_point (:152-180)
-        const double Z = info[2 * best + 1];
-        const double X = Z * ((double)R.x - (double)P.cx) / (double)P.f;
-        const double Y = Z * ((double)R.y - (double)P.cy) / (double)P.f;
-        R.X = (float)X; R.Y = (float)Y; R.Z = (float)Z;
-        // calculate_pre_grasp_point (:754-819)
-        const double nrm = sqrt(X * X + Y * Y + Z * Z);
-        if (!(nrm > 0.0) || !std::isfinite(nrm)) { R.has_pre = 0; return; }  // reference: exception -> None
-        const double dxn = X / nrm, dyn = Y / nrm;
-        const LgWin& bw = all_win[b];          // host bit rows exist for the bounding-box rows only
-        const int hy = bw.by1 - bw.by0 + 1;
-        const unsigned long long* hb = all_bits + ((size_t)b * H + (hy > 0 ? bw.by0 : 0)) * WW;
-        bool done = false;
-        for (int step = 0; step < 5 && !done; step++) {
-            // np.arange(0.05, 0.10, 0.01)[step] = start + step * ((start + delta) - start)
-            const double dist = 0.05 + (double)step * ((0.05 + 0.01) - 0.05);
-            const double tx = X - dxn * dist, ty = Y - dyn * dist, tz = Z;
-            const int u = (int)((tx * (double)P.f / tz) + (double)P.cx);
-            const int v = (int)((ty * (double)P.f / tz) + (double)P.cy);
-            if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
-            if (!(hy > 0 && lg_host_ellipse_hit_band(hb, hy, W, WW, bw.bx0 >> 6, bw.bx1 >> 6, u, v - bw.by0, pre_se))) {
-                const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
-                if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
-            }
-        }
-        if (!done) { R.pX = (float)(X - dxn * 0.10); R.pY = (float)(Y - dyn * 0.10); R.pZ = (float)Z; }
-        R.has_pre = 1;
-    });
+    memcpy(results, h->res_host, sizeof(lg_grasp_result) * B);
     if (trace && !piped) {
         float a[5] = {0};
         for (int i = 1; i <= 4; i++) hipEventElapsedTime(&a[i], tev[0], tev[i]);

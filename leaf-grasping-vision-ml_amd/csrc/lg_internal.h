@@ -107,6 +107,21 @@ void lg_launch_topk(const float* trad, const uint8_t* valid, const float* depth,
 void lg_launch_gather(const float* depth, const uint8_t* mask, const float* const* maps_dev, int B, int H, int W, int k,
                       const int32_t* xy, const int32_t* n, float* patches, bool haloed, hipStream_t s);
 
+// The host half of select_grasp_point on the device (lg_finish_kernel): CNN rescoring of the candidates, 3-D point, pre-grasp point
+struct LgFinishArgs {
+    const int32_t* cand_n;        // [B]
+    const int32_t* cand_xy;       // [B][K][2]
+    const float* cand_info;       // [B][K][2] traditional score, depth at the candidate
+    const float* logits;          // [B][K] (read only when use_cnn)
+    const LgFrameParams* fp;      // [B] (theta)
+    const unsigned long long* bits;   // [B][H][WW] mask bit rows
+    lg_grasp_result* out;         // [B] DEVICE
+    int B, H, W, WW, K, use_cnn, mask_is_bool;
+    double cx, cy, f;
+    LgSeSpans se;                 // (2 * pregrasp_clearance + 1) ellipse
+};
+void lg_launch_finish(const LgFinishArgs& a, hipStream_t s);
+
 // host-side contour analysis on the bit-packed mask (lg_contour.cpp)
 // returns 1 and fills out[0..4] = angle(rad,(0,pi]), major, minor, cx, cy ; 0 if the mask is empty
 int lg_host_orientation(const unsigned long long* bits, int H, int W, int WW, double* out);

@@ -1199,6 +1199,111 @@ void lg_launch_final(const LgFinalArgs& a_in, hipStream_t s, hipEvent_t ev_start
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, a);
 }
 
+// ============================================================================ the tail of select_grasp_point, per frame
+// grasp_point_selector.py:205-245 after the candidates exist: CNN rescoring (ml = tanh(3 sigmoid(logit)) / 2 + 1/2, confidence
+// weights, "take it if the combined score beats the best so far", :210-237), get_3d_grasp_point (:152-180) and
+// calculate_pre_grasp_point (:754-819: five probes of the leaf mask dilated by the clearance ellipse along the viewing ray,
+// fallback at 0.10 m).  One wave per frame; the same float64 operations in the same order as the host code this replaces (fp
+// contraction off), the selection loop sequential in lane 0 -- the call no longer ships candidate lists, logits and bit rows to
+// the host and walks the frames there (0.1 ms of host work + five copies per 256-frame call, with the GPU idle behind them).
+__global__ __launch_bounds__(64) void lg_finish_kernel(LgFinishArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double s_comb[64];
+    __shared__ int s_elig[64], s_best, s_ml;
+    __shared__ double s_bs;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = a.cand_n[b], K = a.K, H = a.H, W = a.W, WW = a.WW;
+    lg_grasp_result R;
+    R.found = 0; R.x = 0; R.y = 0; R.X = 0.f; R.Y = 0.f; R.Z = 0.f; R.has_pre = 0; R.pX = 0.f; R.pY = 0.f; R.pZ = 0.f;
+    R.n_candidates = n; R.ml_used = 0; R.best_score = 0.f; R.theta = a.fp[b].theta;
+    if (n <= 0) {   // reference: "No valid candidate points found" -> (None, None, None)
+        if (lane == 0) a.out[b] = R;
+        return;
+    }
+    const int32_t* xy = a.cand_xy + (size_t)b * K * 2;
+    const float* info = a.cand_info + (size_t)b * K * 2;
+    const bool rescoring = a.use_cnn && n > 1;
+    double comb = 0.0;
+    int elig = 0;
+    if (rescoring && lane < n) {
+        const int x = xy[2 * lane], y = xy[2 * lane + 1];
+        if (!(a.mask_is_bool && (x < 16 || y < 16 || x + 16 > W || y + 16 > H))) {
+            const double logit = (double)a.logits[(size_t)b * K + lane];
+            const double sg = 1.0 / (1.0 + exp(-logit));
+            const double ml = tanh(sg * 3.0) * 0.5 + 0.5;               // :133-136
+            const double conf = 1.0 - fabs(ml - 0.5) * 2.0;              // :222
+            const double wml = fmin(0.3, conf * 0.6);                    // :223
+            comb = (1.0 - wml) * (double)info[2 * lane] + wml * ml;      // :226
+            elig = 1;
+        }
+    }
+    s_comb[lane] = comb;
+    s_elig[lane] = elig;
+    __syncthreads();
+    if (lane == 0) {
+        int best = 0, ml_used = 0;
+        double best_score = (double)info[0];  // candidate 0's traditional score (:205-206)
+        if (rescoring)
+            for (int i = 0; i < n; i++)
+                if (s_elig[i] && s_comb[i] > best_score) { best_score = s_comb[i]; best = i; ml_used = 1; }
+        s_best = best; s_ml = ml_used; s_bs = best_score;
+    }
+    __syncthreads();
+    const int best = s_best;
+    R.found = 1;
+    R.ml_used = s_ml;
+    R.x = xy[2 * best]; R.y = xy[2 * best + 1];
+    R.best_score = (float)s_bs;
+    // get_3d_grasp_point (:152-180)
+    const double Z = (double)info[2 * best + 1];
+    const double X = Z * ((double)R.x - a.cx) / a.f;
+    const double Y = Z * ((double)R.y - a.cy) / a.f;
+    R.X = (float)X; R.Y = (float)Y; R.Z = (float)Z;
+    // calculate_pre_grasp_point (:754-819)
+    const double nrm = sqrt(X * X + Y * Y + Z * Z);
+    if (!(nrm > 0.0) || !isfinite(nrm)) {    // reference: exception -> None
+        if (lane == 0) a.out[b] = R;
+        return;
+    }
+    const double dxn = X / nrm, dyn = Y / nrm;
+    const unsigned long long* fb = a.bits + (size_t)b * H * WW;
+    bool done = false;
+    for (int step = 0; step < 5 && !done; step++) {
+        // np.arange(0.05, 0.10, 0.01)[step] = start + step * ((start + delta) - start)
+        const double dist = 0.05 + (double)step * ((0.05 + 0.01) - 0.05);
+        const double tx = X - dxn * dist, ty = Y - dyn * dist, tz = Z;
+        const int u = (int)((tx * a.f / tz) + a.cx);
+        const int v = (int)((ty * a.f / tz) + a.cy);
+        if (!(u >= 0 && u < W && v >= 0 && v < H)) continue;
+        // dilated[v, u] != 0  <=>  some set pixel under the ellipse centred there: lane i tests row i of the structuring element
+        bool hit = false;
+        if (lane < a.se.n && a.se.lo[lane] <= a.se.hi[lane]) {
+            const int y = v + lane - a.se.anchor;
+            const int x0 = max(u + a.se.lo[lane], 0), x1 = min(u + a.se.hi[lane], W - 1);
+            if (y >= 0 && y < H && x0 <= x1) {
+                const unsigned long long* row = fb + (size_t)y * WW;
+                for (int w = x0 >> 6; w <= (x1 >> 6); w++) {
+                    unsigned long long m = ~0ull;
+                    if (w == (x0 >> 6)) m &= ~0ull << (x0 & 63);
+                    if (w == (x1 >> 6)) m &= ~0ull >> (63 - (x1 & 63));
+                    hit |= (row[w] & m) != 0ull;
+                }
+            }
+        }
+        if (__ballot(hit) == 0ull) {
+            const double dg = sqrt((tx - X) * (tx - X) + (ty - Y) * (ty - Y));
+            if (dg >= 0.05) { R.pX = (float)tx; R.pY = (float)ty; R.pZ = (float)tz; done = true; }
+        }
+    }
+    if (!done) { R.pX = (float)(X - dxn * 0.10); R.pY = (float)(Y - dyn * 0.10); R.pZ = (float)Z; }
+    R.has_pre = 1;
+    if (lane == 0) a.out[b] = R;
+}
+
+void lg_launch_finish(const LgFinishArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(lg_finish_kernel, dim3(a.B), dim3(64), 0, s, a);
+}
+
 // ============================================================================ ImageProcessor.smooth_depth on its own
 // image_processor.py:56-64: F.pad(depth, size // 2 on every side, 'reflect') then F.conv2d with the size x size Gaussian (a
 // cross-correlation; the kernel is symmetric).  Output (H + 2P - S + 1) x (W + 2P - S + 1), P = S / 2: the input's shape for odd
