@@ -63,7 +63,7 @@ struct lg_ctx {
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
-    hipEvent_t ev_orient = nullptr, ev_side = nullptr, ev_export = nullptr;
+    hipEvent_t ev_orient = nullptr, ev_side = nullptr;
     int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -306,8 +306,7 @@ int lg_create(int device, lg_handle* out) {
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_export, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
         g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
@@ -373,7 +372,6 @@ int lg_destroy(lg_handle h) {
     lg_orient_free(h->orient);
     if (h->ev_orient) hipEventDestroy(h->ev_orient);
     if (h->ev_side) hipEventDestroy(h->ev_side);
-    if (h->ev_export) hipEventDestroy(h->ev_export);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -501,11 +499,10 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     return LG_OK;
 }
 
-// Bit rows of the bounding boxes + the windows to the host (pre-grasp clearance probes at the end of lg_select_grasp; contour
-// analysis of frames the device kernel hands back).  `after`: an event on the caller's stream the export has to wait for --
-// the export writes pinned host memory over PCIe and slows every memory-bound kernel beside it about 4x (the sweeps' share of
-// the step went 0.26 -> 0.52 ms with it running beside them), so lg_select_grasp queues it behind the top-k, beside the
-// MFMA-bound CNN, instead of beside the sweeps; nullptr: right away (somebody is about to wait for it).
+// Bit rows of the bounding boxes + the windows to the host: only for the host contour analysis (LG_HOST_ORIENT, or frames the
+// device orientation kernel hands back) -- since round 3 the pre-grasp probes run on the device (lg_finish_kernel) and a normal
+// call exports nothing.  The export writes pinned host memory over PCIe and slows every memory-bound kernel beside it about 4x,
+// which is why it is only queued when somebody is about to wait for it.  `after`: an event to wait for first, or nullptr.
 int enq_export(lg_ctx* h, const Plan& pl, int off, int n, hipEvent_t after) {
     const size_t words = (size_t)pl.H * pl.WW;
     if (after) LG_HIP(h, hipStreamWaitEvent(h->copy_stream, after, 0));
