@@ -148,7 +148,7 @@ def _time_config(dev, L, lib, params, P, m_np, d_np, B, H, W, steps):
     sel.select_grasp_points_batch(m, d)
     torch.cuda.synchronize(dev)
     kern = {}
-    for name in ("prep", "bbox", "orient", "stem", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
+    for name in ("prep", "bbox", "orient", "stem", "dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
         n, ms = C.c_int(0), C.c_double(0.0)
         lib.lg_profile_read(sel._h, name.encode(), C.byref(n), C.byref(ms))
         if n.value:
@@ -361,7 +361,7 @@ def main():
     run_steps(2 * len(sels))
     torch.cuda.synchronize(dev)
     kern_all = {}
-    for name in ("prep", "bbox", "orient", "stem", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
+    for name in ("prep", "bbox", "orient", "stem", "dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "dt_border", "final", "topk", "gather", "cnn"):
         tot_n, tot_ms = 0, 0.0
         for sel in sels:
             n, ms = C.c_int(0), C.c_double(0.0)
@@ -570,7 +570,7 @@ def main():
                 prun(2 * len(psels))
                 torch.cuda.synchronize(dev)
                 pk = {}
-                for name in ("dt_fwd", "dt_bwd", "final", "topk", "gather", "cnn"):
+                for name in ("dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "final", "topk", "gather", "cnn"):
                     tn_, tm_ = 0, 0.0
                     for ps_ in psels:
                         n_, ms_ = C.c_int(0), C.c_double(0.0)

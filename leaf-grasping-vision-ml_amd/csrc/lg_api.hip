@@ -63,7 +63,11 @@ struct lg_ctx {
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
-    hipEvent_t ev_orient = nullptr, ev_side = nullptr;
+    hipEvent_t ev_orient = nullptr, ev_side = nullptr, ev_search = nullptr;
+    int opt_dt_algo = 0;            // LG_DT_SEARCH_ALGO=1: one-level row search at every batch size; 2: anchors + bands (3 / 4: with four / one
+                                    // anchor rows per lane); 0: by batch size
+    int opt_dt_search = 2;          // LG_DT_SEARCH=0: d_in by the two sweeps for every frame; 1: by the row search wherever it applies;
+                                    // 2 (default): per frame, the search while the batch's estimated search work stays below the sweeps' latency
     int prof_on = 0;  // 0 off, 1 every kernel (event pairs on the stream), 2 only launches that stamp their own events
     std::vector<LgProfSlot> prof;
     int host_threads = 8;
@@ -306,7 +310,8 @@ int lg_create(int device, lg_handle* out) {
         hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_orient, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_search, hipEventDisableTiming) != hipSuccess) {
         g_create_err = std::string("lg_create: stream / event creation -> ") + hipGetErrorString(hipGetLastError());
         delete h;
         return LG_ERR_HIP;
@@ -337,6 +342,8 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e)) & 3;   // (both bits leave the results unchanged)
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
+    if (const char* e = getenv("LG_DT_SEARCH")) h->opt_dt_search = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(4, atoi(e)));
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LG_CNN_CUS")) {
         const int n = atoi(e);
@@ -372,6 +379,7 @@ int lg_destroy(lg_handle h) {
     lg_orient_free(h->orient);
     if (h->ev_orient) hipEventDestroy(h->ev_orient);
     if (h->ev_side) hipEventDestroy(h->ev_side);
+    if (h->ev_search) hipEventDestroy(h->ev_search);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -473,7 +481,7 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     {
         ProfScope ps(h, "bbox", s);
-        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, s);
+        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, h->opt_dt_search, s);
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
@@ -519,7 +527,26 @@ int enq_export(lg_ctx* h, const Plan& pl, int off, int n, hipEvent_t after) {
 
 // forward + backward distance sweeps (+ frame-border maxima and stem bits when they do not run on the side stream)
 int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
-    const size_t px = (size_t)pl.H * pl.W;
+    const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
+    // d_in by the row search for the frames lg_bbox_kernel picked (LgWin::search_in), on a stream of its own beside the sweeps of
+    // the other frames (and the d_out sweeps of the few frames that need them): throughput-bound work on every CU next to
+    // latency-bound work on one workgroup per frame.  Inside the sub-batch pipeline (whose stages own the side streams): in line.
+    hipStream_t ss = (s == h->s_dt[0] || s == h->s_dt[1]) ? s : h->s_dt[1];
+    if (h->opt_dt_search) {
+        if (ss != s) LG_HIP(h, hipStreamWaitEvent(ss, h->ev_prep, 0));
+        {
+            ProfScope ps(h, "dt_hrun", ss);
+            lg_launch_hrun(h->bits + off * words, h->tmp + 2 * off * px, h->win + off, n, pl.H, pl.W, pl.WW, ss);
+        }
+        // one-level search up to 64 frames (one launch, the device is not full), anchors + bands above (fewer evaluations)
+        const int algo = h->opt_dt_algo ? h->opt_dt_algo : (n <= 64 ? 1 : 2);
+        for (int phase = 0; phase < (algo == 1 ? 1 : 2); phase++) {
+            ProfScope ps(h, phase ? "dt_band" : "dt_search", ss);
+            lg_launch_dtsearch(phase, algo, h->bits + off * words, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
+                               h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, pl.WW, ss);
+        }
+        if (ss != s) LG_HIP(h, hipEventRecord(h->ev_search, ss));
+    }
     {
         ProfScope ps(h, "dt_fwd", s);
         if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, h->win + off, n,
@@ -531,6 +558,7 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
         lg_launch_dt(true, pl.mask + off * px, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
                      h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, s);
     }
+    if (h->opt_dt_search && ss != s) LG_HIP(h, hipStreamWaitEvent(s, h->ev_search, 0));
     if (!h->opt_side_tail) return enq_tail(h, pl, off, n, s);
     return LG_OK;
 }
@@ -801,7 +829,7 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
     lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
     double o[5];
     if (h->orient) {   // the device analysis; a mask with more runs than its scratch holds falls through to the host code
-        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, s);
+        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, 0, s);
         lg_launch_orient(h->orient, h->bits, h->win, h->fp_dev, 0, 1, H, W, WW, s);
         LG_HIP(h, hipMemcpyAsync(h->orient->h_out, h->orient->out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
         LG_HIP(h, hipMemcpyAsync(h->orient->h_status, h->orient->status, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -14,6 +14,11 @@
 #define LG_INIT0 0x1FFFFFFFu  // INT_MAX >> 2 : OpenCV's border initialiser
 #define LG_INF 0x3FFFFFFFu    // "no path yet" inside the DT sweeps (never wins against a real distance)
 #define LG_NOSRC 0x20000000u  // values >= this after the backward sweep mean: image has no source pixel
+#define LG_HCAP 16383u        // run distance of a row without any zero pixel in the image (row search; W <= 8192)
+// lg_bbox_kernel, search_mode 2: a frame's d_in comes from the row search while B * area^1.5 <= this * (rows of its bounding box)
+#ifndef LG_SEARCH_BUDGET
+#define LG_SEARCH_BUDGET 1.7e7f
+#endif
 
 #define LG_MAX_GAUSS 15   // largest smoothing kernel lg_smooth_depth takes (the fused plane kernel: 1, 3, 5, 7)
 struct LgGaussTaps { float k[LG_MAX_GAUSS]; };   // 1-D factor of ImageProcessor's Gaussian (by value in the kernel arguments)
@@ -40,7 +45,9 @@ struct LgWin {
     int wx0, nw, wy0, wy1;   // window: first column, active waves (64*E columns each), row range
     int bx0, bx1, by0, by1;  // bounding box of the mask (bx1 < bx0: empty mask -> window = whole frame)
     int skip_out;            // 1: max d_out cannot lie inside the window (see lg_bbox_kernel): the d_out sweeps of this frame are skipped
-    int pad_[3];
+    int search_in;           // 1: d_in of this frame comes from the row search (lg_hrun_kernel + lg_dtsearch_kernel), its d_in sweeps are skipped
+    int area;                // set bits of the mask
+    int pad_[1];
 };
 
 struct LgFrameParams {  // per frame: leaf orientation, written by lg_orient_kernel (or by the host analysis for frames it hands back)
@@ -93,7 +100,16 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
                          int bottom_start, const LgSeSpans& se, hipStream_t s);
 // columns per sweep wave / waves per sweep workgroup for width W (0 if unsupported)
 int lg_dt_geometry(int W, int* waves);
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, hipStream_t s);
+// search_mode: 0 = d_in by the two sweeps for every frame, 1 = by the row search wherever it applies (a non-empty mask with
+// at least one zero pixel), 2 = the row search when the batch's estimated search work stays below the sweeps' latency
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s);
+// d_in without the row-sequential sweeps (frames with LgWin::search_in): horizontal run distances of the bounding-box rows into
+// `tmp` (the d_in half of the sweep workspace, as uint16), then the bounded search over rows, which writes distance_map inside
+// the window and the maximum into maxfix[b][0]
+void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* win, int B, int H, int W, int WW, hipStream_t s);
+// algo 1: one-level search (phase 0 only); algo 2: phase 0 = anchor rows (every 8th), phase 1 = the rows between them
+int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
+                       const LgWin* win, int B, int H, int W, int WW, hipStream_t s);
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,
                  int H, int W, hipStream_t s);
 // max d_out outside the sweep windows (closed-form chamfer norm on the frame border) -> atomicMax into maxfix[b][1]

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <limits.h>
+#include <algorithm>
 #include <stdlib.h>
 
 // ============================================================================ helpers
@@ -264,13 +265,13 @@ __device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form 
 }
 // One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).
 __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
-                                                      int H, int W, int WW, int wc, int nw_max) {
-    __shared__ int s_b[4];
+                                                      int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit) {
+    __shared__ int s_b[5];
     const int frame = blockIdx.x, t = threadIdx.x;
-    if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; }
+    if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; s_b[4] = 0; }
     __syncthreads();
     const unsigned long long* fb = bits + (size_t)frame * H * WW;
-    int x0 = INT_MAX, x1 = -1, y0 = INT_MAX, y1 = -1;
+    int x0 = INT_MAX, x1 = -1, y0 = INT_MAX, y1 = -1, cnt = 0;
     for (int y = t; y < H; y += 256) {
         const unsigned long long* row = fb + (size_t)y * WW;
         int first = -1, last = -1;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* 
             if (v) {
                 if (first < 0) first = 64 * w + __builtin_ctzll(v);
                 last = 64 * w + 63 - __builtin_clzll(v);
+                cnt += __popcll(v);
             }
         }
         if (first >= 0) { x0 = min(x0, first); x1 = max(x1, last); y0 = min(y0, y); y1 = max(y1, y); }
@@ -286,16 +288,25 @@ __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* 
     if (x1 >= 0) {
         atomicMin(&s_b[0], x0); atomicMax(&s_b[1], x1);
         atomicMin(&s_b[2], y0); atomicMax(&s_b[3], y1);
+        atomicAdd(&s_b[4], cnt);
     }
     __syncthreads();
     if (t == 0) {
         LgWin w;
         w.bx0 = s_b[0]; w.bx1 = s_b[1]; w.by0 = s_b[2]; w.by1 = s_b[3];
+        w.area = s_b[4];
+        w.search_in = 0;
         if (w.bx1 < 0) {   // empty mask: no window (d_out has no source: the closed form of the whole frame applies)
             w.bx0 = 0; w.bx1 = -1; w.by0 = 0; w.by1 = -1;
             w.wx0 = 0; w.nw = nw_max; w.wy0 = 0; w.wy1 = H;
             w.skip_out = 0;
         } else {
+            // d_in by the row search (lg_dtsearch_kernel) needs a zero pixel in the image (a frame without one has OpenCV's
+            // border-initialised result, which only the sweeps produce); its work grows like area^1.5 (pixels x their depth)
+            // while the sweeps' time is set by the window's rows: `search_limit` is where the two meet for this batch.
+            const float a = (float)w.area;
+            w.search_in = (search_mode != 0 && (long long)w.area < (long long)H * W &&
+                           (search_mode == 1 || a * __builtin_sqrtf(a) <= search_limit * (float)(w.by1 - w.by0 + 1))) ? 1 : 0;
             w.wx0 = (w.bx0 / LG_TW) * LG_TW;
             w.nw = (w.bx1 + 1 - w.wx0 + wc - 1) / wc;
             w.wy0 = (w.by0 / LG_TH) * LG_TH;
@@ -312,15 +323,20 @@ __global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* 
             // (strictly larger: the corner that achieves it then lies outside the window, on a border line lg_dout_border_kernel walks)
             w.skip_out = lg_norm5(gx, gy) > ub_in ? 1 : 0;
         }
-        w.pad_[0] = w.pad_[1] = w.pad_[2] = 0;
+        w.pad_[0] = 0;
         wins[frame] = w;
     }
 }
 
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s) {
     int nw = 0;
     const int wc = lg_dt_geometry(W, &nw);
-    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(256), 0, s, bits, win, H, W, WW, wc, nw);
+    // mode 2: the search's time grows like (frames in the batch) x area^1.5 -- 0.8 ms for 256 benchmark leaves of 93 k pixels --,
+    // the sweeps take ~1.65 us per row of the window whatever the batch (one workgroup per frame): a frame is searched while
+    // B * area^1.5 <= LG_SEARCH_BUDGET * rows.  LG_DT_SEARCH_LIMIT=<x> replaces LG_SEARCH_BUDGET / B (experiments).
+    static const float env_limit = getenv("LG_DT_SEARCH_LIMIT") ? (float)atof(getenv("LG_DT_SEARCH_LIMIT")) : 0.0f;
+    const float limit = env_limit > 0.0f ? env_limit : LG_SEARCH_BUDGET / (float)(B > 0 ? B : 1);
+    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(256), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit);
 }
 
 // ============================================================================ max d_out outside the sweep window
@@ -434,6 +450,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
     const int nwa = win.nw;
     if (wave >= nwa) return;
     if (which == 1 && win.skip_out) return;   // max d_out lies on the frame border (lg_bbox_kernel): whole workgroup, before any barrier
+    if (which == 0 && win.search_in) return;  // d_in of this frame comes from lg_dtsearch_kernel
     const int wx0 = win.wx0, wxe = wx0 + nwa * WC;   // window columns [wx0, wxe); columns >= W are outside the image
     const int wy0 = win.wy0, HW = win.wy1 - win.wy0; // window rows
     const size_t fo = (size_t)frame * H * W;
@@ -711,6 +728,458 @@ int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, 
     else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
     else return -1;
     return 0;
+}
+
+// ============================================================================ d_in without the sweeps: run distances + row search
+// The two raster passes of the 5x5 chamfer transform give  d(p) = min over zero pixels q of N(p - q)  with the closed-form
+// chamfer norm N (LgWin; pinned in tests/test_oracle_c.py), and N is monotone in |dx| and in |dy|.  For a fixed row y' only the
+// zero pixel of that row nearest to column x can matter:
+//     d(x, y) = min over rows y' of N(h[y'][x], |y - y'|),   h[y'][x] = distance from x to the nearest zero pixel of row y'
+// h comes straight from the bit rows (count-leading/trailing-zeros, no sequential dependence: lg_hrun_kernel); the search over
+// rows is bounded by N(., dy) >= a * dy: rows further away than the best value found so far cannot improve it
+// (lg_dtsearch_kernel).  Every leaf pixel is independent -- the work spreads over all CUs instead of one workgroup per frame
+// walking the window's rows one after the other (~1 us per row).  Rows outside [by0 - 1, by1 + 1] never matter: the rows next
+// to the bounding box are all zero (h = 0) and nearer than any row beyond them.  Out-of-image pixels are not sources.
+// Both kernels: workgroup ids are dealt round-robin to the 8 XCDs, and a frame's workgroups all carry the same id % 8, so a
+// frame's run distances are written and read through ONE XCD's L2.  grid = 8 * G * ceil(B / 8).
+__device__ __forceinline__ bool lg_frame_of_block(int G, int B, int* frame, int* j) {
+    const int id = (int)blockIdx.x, q = id >> 3;
+    const int fq = q / G;
+    *frame = (id & 7) + 8 * fq;
+    *j = q - fq * G;
+    return *frame < B;
+}
+
+__device__ __forceinline__ unsigned long long lg_readlane_u64(unsigned long long v, int l) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+// One wave per row of [by0 - 1, by1 + 1]: lane k loads word k of the bounding box (one coalesced load, nothing else is read:
+// in-image words outside the bounding box are all zero pixels), the nearest word with a zero pixel on either side of a word
+// comes from a ballot, and the row's words are then written one after the other, lane = pixel.  Rows wider than 64 words
+// (W > 4096 and a leaf spanning them) are processed in 64-word pieces whose neighbours are looked up in memory.
+__global__ __launch_bounds__(256) void lg_hrun_kernel(const unsigned long long* __restrict__ bits, const LgWin* __restrict__ wins,
+                                                      uint32_t* __restrict__ tmp, int H, int W, int WW, int G, int B) {
+    int frame, j;
+    if (!lg_frame_of_block(G, B, &frame, &j)) return;
+    const LgWin w = wins[frame];
+    if (!w.search_in) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r0 = max(w.by0 - 1, 0), r1 = min(w.by1 + 1, H - 1);
+    const int w0 = w.bx0 >> 6, w1 = w.bx1 >> 6;
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    uint16_t* hd = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W);
+    const int tail = W & 63;   // the last word's bits beyond the image are neither leaf nor source
+    for (int y = r0 + j * 4 + wave; y <= r1; y += 4 * G) {
+        const unsigned long long* row = fb + (size_t)y * WW;
+        auto zeros = [&](int k) -> unsigned long long {   // zero pixels of word k (k in [0, WW))
+            unsigned long long z = ~row[k];
+            if (k == WW - 1 && tail) z &= (1ull << tail) - 1ull;
+            return z;
+        };
+        for (int c0 = w0; c0 <= w1; c0 += 64) {
+            const int nc = min(64, w1 - c0 + 1);
+            const unsigned long long z = lane < nc ? zeros(c0 + lane) : 0ull;
+            const unsigned long long nz = __ballot(z != 0ull);
+            // nearest zero pixel left of the piece's first pixel / right of its last one, as distances from those pixels
+            unsigned edge_l = LG_HCAP, edge_r = LG_HCAP;
+            for (int k = c0 - 1; k >= 0; k--) {
+                const unsigned long long zk = zeros(k);
+                if (zk) { edge_l = 64u * (unsigned)(c0 - 1 - k) + (unsigned)__builtin_clzll(zk) + 1u; break; }
+            }
+            for (int k = c0 + nc; k < WW; k++) {
+                const unsigned long long zk = zeros(k);
+                if (zk) { edge_r = 64u * (unsigned)(k - c0 - nc) + (unsigned)__builtin_ctzll(zk) + 1u; break; }
+            }
+            for (int i = 0; i < nc; i++) {
+                const unsigned long long zi = lg_readlane_u64(z, i);
+                const unsigned long long ml = i ? nz & ((1ull << i) - 1ull) : 0ull, mr = i < 63 ? nz >> (i + 1) : 0ull;
+                unsigned lc, rc;
+                if (ml) {
+                    const int k = 63 - __builtin_clzll(ml);
+                    lc = 64u * (unsigned)(i - 1 - k) + (unsigned)__builtin_clzll(lg_readlane_u64(z, k)) + 1u;
+                } else {
+                    lc = min(LG_HCAP, 64u * (unsigned)i + edge_l);
+                }
+                if (mr) {
+                    const int k = i + 1 + __builtin_ctzll(mr);
+                    rc = 64u * (unsigned)(k - i - 1) + (unsigned)__builtin_ctzll(lg_readlane_u64(z, k)) + 1u;
+                } else {
+                    rc = min(LG_HCAP, 64u * (unsigned)(nc - 1 - i) + edge_r);
+                }
+                const unsigned long long zl = zi << (63 - lane);   // pixels <= lane, the pixel itself in bit 63
+                const unsigned long long zr = zi >> lane;          // pixels >= lane, the pixel itself in bit 0
+                const unsigned dl = zl ? (unsigned)__builtin_clzll(zl) : (unsigned)lane + lc;
+                const unsigned dr = zr ? (unsigned)__builtin_ctzll(zr) : (unsigned)(63 - lane) + rc;
+                const int x = 64 * (c0 + i) + lane;
+                if (x < W) hd[(unsigned)(y * W) + (unsigned)x] = (uint16_t)min(min(dl, dr), LG_HCAP);
+            }
+        }
+    }
+}
+
+// N(h, dy) as the maximum of its four linear pieces (a norm is the maximum of its supporting functionals; for this mask
+// 2a <= c <= a + b makes them a*M + (c-2a)*m and (c-b)*M + (2b-c)*m with M, m the larger / smaller of the two arguments):
+// dy is wave-uniform, so its four products live in scalar registers and a candidate costs four 24-bit multiply-adds.
+#define LG_N5_AL (LG_C5 - 2u * LG_A5)   // 12904
+#define LG_N5_BE (LG_C5 - LG_B5)        // 52226
+#define LG_N5_GA (2u * LG_B5 - LG_C5)   // 39524
+struct LgH4 { uint32_t a, al, be, ga; };   // h times the four coefficients: shared by the lane's four pixels
+__device__ __forceinline__ LgH4 lg_h4(uint32_t h) {   // h <= LG_HCAP
+    LgH4 r = {h << 16, (uint32_t)__umul24(h, LG_N5_AL), (uint32_t)__umul24(h, LG_N5_BE), (uint32_t)__umul24(h, LG_N5_GA)};
+    // (keeps the three products: hipcc otherwise re-fuses them into one multiply-add per pixel whose scalar addend costs a move)
+    asm volatile("" : "+v"(r.al), "+v"(r.be), "+v"(r.ga));
+    return r;
+}
+__device__ __forceinline__ uint32_t lg_norm5_h(const LgH4& h, uint32_t dy) {   // dy <= 16384 (wave-uniform): below 2^32
+    const uint32_t t0 = h.a + __umul24(dy, LG_N5_AL);
+    const uint32_t t1 = h.al + (dy << 16);
+    const uint32_t t2 = h.be + __umul24(dy, LG_N5_GA);
+    const uint32_t t3 = h.ga + __umul24(dy, LG_N5_BE);
+    return max(max(t0, t1), max(t2, t3));
+}
+
+// Workgroup = one 64 x 16 tile of the window at a time (the score-plane kernel's tiles), wave = 4 rows, lane = column: a
+// candidate row's h is loaded once (128 contiguous bytes per wave) and serves the lane's four pixels.
+__global__ __launch_bounds__(256) void lg_dtsearch_kernel(const unsigned long long* __restrict__ bits,
+                                                          const LgWin* __restrict__ wins, const uint32_t* __restrict__ tmp,
+                                                          float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
+                                                          int W, int WW, int wc, int G, int B) {
+    int frame, j;
+    if (!lg_frame_of_block(G, B, &frame, &j)) return;
+    const LgWin w = wins[frame];
+    if (!w.search_in) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wxe = min(W, w.wx0 + w.nw * wc);
+    const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + LG_TH - 1) / LG_TH;
+    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);   // candidate rows
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
+    float* dout = dist_out + (size_t)frame * H * W;
+    uint32_t mx = 0;
+    static_assert(LG_TH == 16, "four waves x four rows");
+    const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
+    for (int tile = j; tile < ntile; tile += G) {
+        const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
+        const int wi = (w.wx0 >> 6) + txi;
+        const int x = 64 * wi + lane, yb = w.wy0 + LG_TH * tyi + 4 * wave;
+        const bool xin = x < W;
+        const unsigned xc = (unsigned)min(x, W - 1);
+        unsigned long long rb[4];   // the tile is word aligned: one word per row, the same for every lane
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[i] = fb[(unsigned)(min(yb + i, H - 1) * WW + wi)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rb[i] = yb + i < H ? rb[i] : 0ull;
+            rb[i] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rb[i] >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)rb[i]);
+        }
+        if (!(rb[0] | rb[1] | rb[2] | rb[3])) {   // no leaf pixel in these four rows: d_in = 0
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (xin && yb + i < H) dout[(unsigned)((yb + i) * W) + xc] = 0.0f;
+            continue;
+        }
+        uint32_t best[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) best[i] = (xin && ((rb[i] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
+        // the four rows themselves (a leaf pixel's own row always lies in [lo, hi]; rows beyond have no leaf pixel and, as
+        // candidates, lose to the all-zero rows lo / hi)
+        {
+            uint32_t h4[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2++) h4[i2] = hd[(unsigned)(max(lo, min(yb + i2, hi)) * W) + xc];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2++) {
+                if (yb + i2 >= lo && yb + i2 <= hi) {
+                    const LgH4 hh = lg_h4(h4[i2]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) best[i] = min(best[i], lg_norm5_h(hh, (uint32_t)(i > i2 ? i - i2 : i2 - i)));
+                }
+            }
+        }
+        // rows above (yb - k) and below (yb + 3 + k), four steps per round so that eight loads are in flight
+        for (int k0 = 1;; k0 += 4) {
+            const int yu0 = yb - k0, yd0 = yb + 3 + k0;
+            if (yu0 < lo && yd0 > hi) break;
+            const uint32_t bm = max(max(best[0], best[1]), max(best[2], best[3]));
+            if (!__any((uint32_t)k0 * LG_A5 < bm)) break;   // N(., dy) >= a * dy >= a * k0 from here on
+            uint32_t hu[4], hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                hu[q] = hd[(unsigned)(max(yu0 - q, lo) * W) + xc];
+                hv[q] = hd[(unsigned)(min(yd0 + q, hi) * W) + xc];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t k = (uint32_t)(k0 + q);
+                const uint32_t bq = max(max(best[0], best[1]), max(best[2], best[3]));
+                // a row whose h is at least the best value everywhere in the wave cannot improve anything: N(h, .) >= a * h
+                if (yu0 - q >= lo && __any((hu[q] << 16) < bq)) {
+                    const LgH4 hh = lg_h4(hu[q]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) best[i] = min(best[i], lg_norm5_h(hh, k + (uint32_t)i));
+                }
+                if (yd0 + q <= hi && __any((hv[q] << 16) < bq)) {
+                    const LgH4 hh = lg_h4(hv[q]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) best[i] = min(best[i], lg_norm5_h(hh, k + (uint32_t)(3 - i)));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            mx = max(mx, best[i]);
+            if (xin && yb + i < H) dout[(unsigned)((yb + i) * W) + xc] = (float)best[i] * (1.0f / 65536.0f);
+        }
+    }
+    mx = lg_wave_max_u32(mx);
+    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
+}
+
+// ---- the same search in two levels.  Along a column the minimising row is monotone in y: for two candidate rows r1 < r2,
+// sign(N(h[r1], |y - r1|) - N(h[r2], |y - r2|)) never decreases with y (checked exhaustively for the mask's norm; it is what
+// makes Hirata's / Meijster's lower-envelope scans work for chamfer metrics).  So if a1 minimises at row y1 and a2 at row
+// y2 > y1 (ANY minimisers), every row y1 < y < y2 has a minimiser in [min(a1, a2), max(a1, a2)].
+//   lg_dtanchor_kernel: rows y % 8 == 0 of the window by the bounded search, recording a minimising row per pixel;
+//   lg_dtband_kernel:   the seven rows between two anchor rows, candidates = the union over the wave's columns of
+//                       [anchor above's row, anchor below's row] -- a dozen rows where the nearest edge stays on one side,
+//                       the leaf's whole thickness where the band crosses its medial axis (once per column).
+// ~5x fewer candidate evaluations than the one-level search at the benchmark's leaf size; same integers.
+template <int NP>   // anchor rows per lane (8 rows apart): 4 shares every candidate row's load among four pixels (large batches);
+                    // 1 gives four times the waves and a quarter of the work per wave (small batches: latency)
+__global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long long* __restrict__ bits,
+                                                          const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
+                                                          float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
+                                                          int W, int WW, int wc, int G, int B) {
+    int frame, j;
+    if (!lg_frame_of_block(G, B, &frame, &j)) return;
+    const LgWin w = wins[frame];
+    if (!w.search_in) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wxe = min(W, w.wx0 + w.nw * wc);
+    constexpr int ROWS = 32 * NP;   // rows per workgroup tile: four waves x NP anchors x 8
+    const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + ROWS - 1) / ROWS;
+    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);   // candidate rows
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
+    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;   // [H / 8][W] minimising rows
+    float* dout = dist_out + (size_t)frame * H * W;
+    uint32_t mx = 0;
+    constexpr int SPAN = 4 * (NP - 1);   // the anchors lie within SPAN rows of the scan's centre
+    const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
+    for (int tile = j; tile < ntile; tile += G) {
+        const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
+        const int wi = (w.wx0 >> 6) + txi;
+        const int x = 64 * wi + lane, ya0 = w.wy0 + ROWS * tyi + 8 * NP * wave;
+        if (ya0 >= w.wy1) continue;   // (wave-uniform)
+        const bool xin = x < W;
+        const unsigned xc = (unsigned)min(x, W - 1);
+        unsigned long long rb[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int y = ya0 + 8 * i;
+            rb[i] = fb[(unsigned)(min(y, H - 1) * WW + wi)];
+            rb[i] = y < w.wy1 ? lg_readlane_u64(rb[i], 0) : 0ull;
+        }
+        unsigned long long anyb = 0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) anyb |= rb[i];
+        uint32_t best[NP];
+        int arow[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            best[i] = (xin && ((rb[i] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
+            arow[i] = ya0 + 8 * i;   // an off-leaf pixel is its own nearest zero pixel
+        }
+        if (anyb) {
+            const int c = ya0 + SPAN;   // scan outwards from here: rows c - k and c + 1 + k
+            for (int k0 = 0;; k0 += 4) {
+                const int yu0 = c - k0, yd0 = c + 1 + k0;
+                if (yu0 < lo && yd0 > hi) break;
+                uint32_t bm = best[0];
+#pragma unroll
+                for (int i = 1; i < NP; i++) bm = max(bm, best[i]);
+                if (!__any((uint32_t)max(k0 - SPAN, 0) * LG_A5 < bm)) break;   // every anchor is at least k0 - SPAN rows away from here on
+                uint32_t hu[4], hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    hu[q] = hd[(unsigned)(min(max(yu0 - q, lo), hi) * W) + xc];
+                    hv[q] = hd[(unsigned)(max(min(yd0 + q, hi), lo) * W) + xc];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t bq = best[0];
+#pragma unroll
+                    for (int i = 1; i < NP; i++) bq = max(bq, best[i]);
+                    const int yu = yu0 - q, yd = yd0 + q;
+                    if (yu >= lo && yu <= hi && __any((hu[q] << 16) < bq)) {
+                        const LgH4 hh = lg_h4(hu[q]);
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            const int dy = ya0 + 8 * i - yu;
+                            const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
+                            arow[i] = v < best[i] ? yu : arow[i];
+                            best[i] = min(best[i], v);
+                        }
+                    }
+                    if (yd >= lo && yd <= hi && __any((hv[q] << 16) < bq)) {
+                        const LgH4 hh = lg_h4(hv[q]);
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            const int dy = ya0 + 8 * i - yd;
+                            const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
+                            arow[i] = v < best[i] ? yd : arow[i];
+                            best[i] = min(best[i], v);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int y = ya0 + 8 * i;
+            mx = max(mx, best[i]);
+            if (xin && y < w.wy1) {
+                dout[(unsigned)(y * W) + xc] = (float)best[i] * (1.0f / 65536.0f);
+                argb[(unsigned)((y >> 3) * W) + xc] = (uint16_t)arow[i];
+            }
+        }
+    }
+    mx = lg_wave_max_u32(mx);
+    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
+}
+
+__device__ __forceinline__ int lg_wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int lg_wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Workgroup tile = 64 columns x 32 rows, wave = the seven rows between the anchor rows ya and ya + 8, lane = column.
+__global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long* __restrict__ bits,
+                                                        const LgWin* __restrict__ wins, const uint32_t* __restrict__ tmp,
+                                                        float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H, int W,
+                                                        int WW, int wc, int G, int B) {
+    int frame, j;
+    if (!lg_frame_of_block(G, B, &frame, &j)) return;
+    const LgWin w = wins[frame];
+    if (!w.search_in) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wxe = min(W, w.wx0 + w.nw * wc);
+    const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + 31) >> 5;
+    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);   // candidate rows
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
+    const uint16_t* argb = hd + (size_t)H * W;
+    float* dout = dist_out + (size_t)frame * H * W;
+    uint32_t mx = 0;
+    const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
+    for (int tile = j; tile < ntile; tile += G) {
+        const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
+        const int wi = (w.wx0 >> 6) + txi;
+        const int x = 64 * wi + lane, ya = w.wy0 + 32 * tyi + 8 * wave;
+        if (ya + 1 >= w.wy1) continue;   // (wave-uniform)
+        const bool xin = x < W;
+        const unsigned xc = (unsigned)min(x, W - 1);
+        unsigned long long rb[7], anyb = 0;
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int y = ya + 1 + r;
+            rb[r] = fb[(unsigned)(min(y, H - 1) * WW + wi)];
+            rb[r] = y < w.wy1 ? lg_readlane_u64(rb[r], 0) : 0ull;
+            anyb |= rb[r];
+        }
+        uint32_t best[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) best[r] = (xin && ((rb[r] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
+        if (anyb) {
+            // this lane's candidate rows: between the minimising rows of its two anchors (the anchor below the last leaf row
+            // would be an off-leaf pixel minimised by itself: every row down to `hi` then).  Every lane walks ITS OWN rows
+            // (row = first + t): along a tilted edge the windows of neighbouring columns are shifted against each other, and a
+            // row shared by the whole wave would have to cover their union -- 64 columns x the edge's slope.  The loads are then
+            // per-lane rows (neighbouring lanes mostly hit the same or the next line; seven evaluations pay for each).
+            const int a1 = argb[(unsigned)((ya >> 3) * W) + xc];
+            const int yb = ya + 8;
+            const int a2 = yb <= w.by1 ? (int)argb[(unsigned)((min(yb, H - 1) >> 3) * W) + xc] : hi;
+            const bool mine = xin && ((anyb >> lane) & 1ull);
+            const int first = max(min(a1, a2), lo);
+            const int len = mine ? min(max(a1, a2), hi) - first + 1 : 0;
+            const int maxlen = lg_wave_max_i32(len);
+            for (int t0 = 0; t0 < maxlen; t0 += 4) {
+                uint32_t hh4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool act = t0 + q < len;
+                    uint32_t bq = best[0];
+#pragma unroll
+                    for (int r = 1; r < 7; r++) bq = max(bq, best[r]);
+                    if (__any(act && (hh4[q] << 16) < bq)) {   // N(h, .) >= a * h: a row that cannot improve any lane is skipped
+                        const LgH4 hh = lg_h4(hh4[q]);
+                        const int yc = first + t0 + q;
+#pragma unroll
+                        for (int r = 0; r < 7; r++) {
+                            const int dy = ya + 1 + r - yc;
+                            const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
+                            best[r] = min(best[r], act ? v : 0xFFFFFFFFu);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const int y = ya + 1 + r;
+            mx = max(mx, best[r]);
+            if (xin && y < w.wy1) dout[(unsigned)(y * W) + xc] = (float)best[r] * (1.0f / 65536.0f);
+        }
+    }
+    mx = lg_wave_max_u32(mx);
+    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
+}
+
+static int lg_search_groups(int B, int per_batch, int lo, int hi) {
+    const int bpad = 8 * ((B + 7) / 8);
+    return std::max(lo, std::min(hi, per_batch / bpad));
+}
+void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
+    const int G = lg_search_groups(B, 2048, 2, 64);
+    hipLaunchKernelGGL(lg_hrun_kernel, dim3(8u * G * ((B + 7) / 8)), dim3(256), 0, s, bits, win, tmp, H, W, WW, G, B);
+}
+// algo 1: the one-level search of every row (one launch: small batches, where the launches' latency counts and the device is
+// not full); algo 2: anchor rows (phase 0), then the rows between them (phase 1); 3 / 4: the same with four / one anchor rows
+// per lane whatever the batch (tests).  Returns 0 when the phase has nothing to launch.
+int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
+                       const LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
+    static const int g_env = getenv("LG_DT_SEARCH_G") ? atoi(getenv("LG_DT_SEARCH_G")) : 0;
+    const int wc = lg_dt_geometry(W, nullptr);
+    const unsigned nb8 = 8u * (unsigned)((B + 7) / 8);
+    if (algo == 1) {
+        if (phase) return 0;
+        const int G = g_env > 0 ? g_env : lg_search_groups(B, 8192, 8, 256);
+        hipLaunchKernelGGL(lg_dtsearch_kernel, dim3(nb8 * G), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, G, B);
+        return 1;
+    }
+    if (phase == 0) {
+        const bool np4 = algo == 3 || (algo == 2 && B >= 128);   // (32 frames: 0.071 vs 0.100 ms with one / four anchors per lane)
+        // workgroups per frame: the window's tiles (64 columns x 128 / 32 rows) when the grid allows -- leaf tiles cluster, and a
+        // workgroup that walks several of them with a fixed stride gets several heavy ones or none
+        const int tiles = ((W + 63) / 64) * ((H + (np4 ? 127 : 31)) / (np4 ? 128 : 32));
+        const int Ga = g_env > 0 ? g_env : std::min(tiles, lg_search_groups(B, 16384, 8, 512));
+        if (np4) hipLaunchKernelGGL(lg_dtanchor_kernel<4>, dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+        else hipLaunchKernelGGL(lg_dtanchor_kernel<1>, dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+        return 1;
+    }
+    const int Gb = g_env > 0 ? g_env : std::min(((W + 63) / 64) * ((H + 31) / 32), lg_search_groups(B, 32768, 8, 512));
+    hipLaunchKernelGGL(lg_dtband_kernel, dim3(nb8 * Gb), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Gb, B);
+    return 1;
 }
 
 // ============================================================================ fused score planes

@@ -130,10 +130,37 @@ def _window_case(rng, H, W, kind):
     return m.astype(np.uint8)
 
 
-def test_windowed_sweeps_are_exact(sel):
+# d_in comes from the two raster sweeps (LG_DT_SEARCH=0) or from the row search (lg_hrun_kernel + one-level / anchors-and-bands
+# search); the library picks per frame and batch size.  Every form must give the oracle's integers: the options are read when a
+# handle is created, so each form gets a selector of its own.
+DT_FORMS = {"auto": {}, "sweeps": {"LG_DT_SEARCH": "0"}, "search1": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "1"},
+            "search2_np4": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "3"}, "search2_np1": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "4"}}
+
+
+@pytest.fixture(scope="module")
+def dt_sels(L):
+    out = {}
+    for name, env in DT_FORMS.items():
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            out[name] = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+            out[name].set_camera_params(O.synthetic_scene(64, 64, 0)[2])
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return out
+
+
+@pytest.mark.parametrize("form", list(DT_FORMS))
+def test_windowed_sweeps_are_exact(dt_sels, form):
     """The distance transforms run on the tile-aligned window around the leaf's bounding box; max d_out outside it comes
     from the closed-form chamfer norm on the frame border.  Both must reproduce the full-frame two-pass transform of the
     oracle bit for bit: distance_map, max d_in and max d_out (the sdf normaliser, grasp_point_selector.py:531-533)."""
+    sel = dt_sels[form]
     rng = np.random.default_rng(77)
     shapes = [(96, 128), (150, 333), (210, 520), (300, 1030), (64, 64), (131, 258)]
     n_windowed = 0
@@ -155,6 +182,46 @@ def test_windowed_sweeps_are_exact(sel):
     assert n_windowed >= 20   # the windowed path was actually exercised
 
 
+@pytest.mark.parametrize("form", ["search1", "search2_np4", "search2_np1"])
+def test_row_search_on_hard_masks(dt_sels, form):
+    """Masks the row search has to get right beyond the window cases: a frame with a single zero pixel, full-width bands (rows
+    without any zero pixel), leaves wider than 64 words' worth of columns is covered at 4K; thin diagonal strips (every
+    column's minimising row differs), a comb (many medial axes), a 17-frame batch mixing all of them with an empty and a full
+    mask (those two go through the sweeps)."""
+    sel = dt_sels[form]
+    H, W = 200, 520
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = []
+    m = np.ones((H, W), np.uint8); m[137, 411] = 0; masks.append(m)
+    m = np.ones((H, W), np.uint8); m[0, 0] = 0; masks.append(m)
+    m = np.ones((H, W), np.uint8); m[H - 1, W - 1] = 0; masks.append(m)
+    m = np.zeros((H, W), np.uint8); m[40:160, :] = 1; masks.append(m)                     # full-width band
+    m = np.zeros((H, W), np.uint8); m[:, 100:400] = 1; masks.append(m)                    # full-height band
+    m = np.ones((H, W), np.uint8); m[:, 0] = 0; masks.append(m)
+    m = np.ones((H, W), np.uint8); m[H - 1, :] = 0; masks.append(m)
+    masks.append((np.abs((yy - 100) - 0.35 * (xx - 260)) < 23).astype(np.uint8))         # diagonal strip
+    masks.append((np.abs((yy - 100) + 1.9 * (xx - 260)) < 60).astype(np.uint8))          # steep strip
+    m = np.zeros((H, W), np.uint8); m[20:180, 30:490] = 1; m[20:150, 60:480:40] = 0; masks.append(m)   # comb
+    m = ((xx % 7 != 0) | (yy % 5 != 0)).astype(np.uint8); masks.append(m)                # lattice of zero pixels
+    rng = np.random.default_rng(5)
+    masks.append((rng.random((H, W)) < 0.97).astype(np.uint8))
+    masks.append((rng.random((H, W)) < 0.5).astype(np.uint8))
+    masks.append((np.hypot(yy - 100, xx - 260) < 95).astype(np.uint8))
+    masks.append(((np.hypot(yy - 100, (xx - 260) / 2.5) < 90) & (np.hypot(yy - 100, xx - 260) > 30)).astype(np.uint8))
+    masks.append(np.zeros((H, W), np.uint8))
+    masks.append(np.ones((H, W), np.uint8))
+    depth = np.full((H, W), 0.5, np.float32)
+    exp = [O.distance_transform(m, 5) for m in masks]
+    for i, m in enumerate(masks):
+        maps, _, _ = sel.score_maps(torch.from_numpy(m).cuda(), torch.from_numpy(depth).cuda())
+        np.testing.assert_array_equal(maps["distance_map"].cpu().numpy(), exp[i], err_msg=f"mask {i}")
+        assert sel.dt_maxima(0)[0] == exp[i].max(), f"mask {i}"
+    mb, _, _ = sel.score_maps(torch.from_numpy(np.stack(masks)).cuda(), torch.from_numpy(np.stack([depth] * len(masks))).cuda())
+    for i in range(len(masks)):
+        np.testing.assert_array_equal(mb["distance_map"][i].cpu().numpy(), exp[i], err_msg=f"batched mask {i}")
+        assert sel.dt_maxima(i)[0] == exp[i].max(), f"batched mask {i}"
+
+
 def test_batch_equals_single(sel):
     H, W = 135, 180
     frames = [O.synthetic_scene(H, W, s) for s in range(5)]
@@ -170,8 +237,10 @@ def test_batch_equals_single(sel):
         np.testing.assert_array_equal(vb[i].cpu().numpy(), vs.cpu().numpy())
 
 
-def test_full_size_1080p_and_4k_distance_transform(sel):
+@pytest.mark.parametrize("form", list(DT_FORMS))
+def test_full_size_1080p_and_4k_distance_transform(dt_sels, form):
     """BASELINE configs 2 and 4: bit-exact chamfer transform at 1080p and 4K + size-independent properties."""
+    sel = dt_sels[form]
     for (H, W), seed in (((1080, 1920), 7), ((2160, 3840), 8)):
         labels, depth, P = O.synthetic_scene(H, W, seed)
         mask = (labels == 1).astype(np.uint8)
