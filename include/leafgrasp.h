@@ -87,6 +87,16 @@ typedef struct lg_params {
     int32_t gaussian_size;                          /* 5: the ImageProcessor's smoothing kernel that _calculate_flatness_map applies
                                                        (:635-657, image_processor.py:25-32,56-64; sigma = size / 6).  1, 3, 5, 7;
                                                        anything else => LG_ERR_UNSUPPORTED (an even size raises in the reference) */
+    int32_t chamfer_init_dist0;                     /* OpenCV's INIT_DIST0, the value cv2.distanceTransform's border cells start from.
+                                                       It only shows in the transform of an image WITHOUT any zero pixel, which is
+                                                       what _calculate_isolation_score asks for (:605-616: other_leaves == 0) and
+                                                       what dist_inside of an all-ones mask is: INIT_DIST0 / 65536 + weight * (distance
+                                                       to the frame).  The constant depends on the OpenCV revision: INT_MAX >> 2
+                                                       (536870911, default; distransform.cpp of the 2.4 / 3.x lines) or INT_MAX
+                                                       (2147483647; revisions that lifted the 8192-pixel ceiling).  The pinned
+                                                       opencv-python 4.10.0.84 is absent here: parity unpinned.
+                                                       Range [INT_MAX >> 2, INT_MAX] */
+    int32_t reserved_;                              /* 0 */
 } lg_params;
 
 /* Raw GraspPointCNN(in_channels=9, attention_type, encoder_filters) state_dict tensors, HOST pointers,

@@ -20,7 +20,7 @@ class LgParams(C.Structure):
         "sdf_w_sdf", "optimal_distance", "access_w_dist", "access_w_dir", "flat_scale", "iso_w_close",
         "iso_w_wide", "iso_ramp_top", "iso_ramp_bottom", "min_edge_distance", "stem_valid_thresh")] + \
         [(n, C.c_int32) for n in ("stem_se", "stem_bottom_div", "top_k", "nms_min_distance",
-                                  "pregrasp_clearance", "mask_is_bool", "gaussian_size")]
+                                  "pregrasp_clearance", "mask_is_bool", "gaussian_size", "chamfer_init_dist0", "reserved_")]
 
 
 _FP = C.POINTER(C.c_float)

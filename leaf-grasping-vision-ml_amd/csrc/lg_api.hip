@@ -280,6 +280,7 @@ void lg_default_params(lg_params* p) {
     p->pregrasp_clearance = 15;
     p->mask_is_bool = 1;
     p->gaussian_size = 5;   // the node's ImageProcessor(..., gaussian_kernel_size=5) (leaf_grasp_node_v3.py:37,66-67)
+    p->chamfer_init_dist0 = (int32_t)LG_INIT0;   // INT_MAX >> 2
 }
 
 static thread_local std::string g_create_err = "null handle";
@@ -550,13 +551,13 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     {
         ProfScope ps(h, "dt_fwd", s);
         if (lg_launch_dt(false, pl.mask + off * px, h->tmp + 2 * off * px, nullptr, h->maxfix + 2 * (size_t)off, h->win + off, n,
-                         pl.H, pl.W, s))
+                         pl.H, pl.W, (uint32_t)pl.P.chamfer_init_dist0, s))
             return fail(h, LG_ERR_UNSUPPORTED, "dt: width");
     }
     {
         ProfScope ps(h, "dt_bwd", s);
         lg_launch_dt(true, pl.mask + off * px, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
-                     h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, s);
+                     h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, (uint32_t)pl.P.chamfer_init_dist0, s);
     }
     if (h->opt_dt_search && ss != s) LG_HIP(h, hipStreamWaitEvent(s, h->ev_search, 0));
     if (!h->opt_side_tail) return enq_tail(h, pl, off, n, s);
@@ -631,7 +632,8 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     {
         // max of the chamfer-3 transform of an all-ones image: INIT + ceil(min(H,W)/2) * 0.955
         uint32_t dmax = (uint32_t)((std::min(H, W) + 1) / 2);
-        float mx = (float)(LG_INIT0 + dmax * LG_A3) * (1.0f / 65536.0f);
+        float mx = (float)((uint32_t)P.chamfer_init_dist0 + dmax * LG_A3) * (1.0f / 65536.0f);
+        a.init0 = (uint32_t)P.chamfer_init_dist0;
         a.iso_inv_max = 1.0f / mx;  // reference divides by (max + 1e-6), which rounds to max in float32
     }
     a.min_edge_distance = P.min_edge_distance; a.stem_valid_thresh = P.stem_valid_thresh;
@@ -663,6 +665,8 @@ int make_plan(lg_ctx* h, Plan& pl, const float* depth, const uint8_t* mask, int 
     // an (H+1) x (W+1) plane there and the fusion raises -> None triple; odd sizes above 7 exceed this kernel's halo
     if (pl.P.gaussian_size < 1 || pl.P.gaussian_size > 7 || (pl.P.gaussian_size & 1) == 0)
         return fail(h, LG_ERR_UNSUPPORTED, "gaussian_size must be 1, 3, 5 or 7 (an even size fails in the reference too: shape mismatch in the fusion)");
+    if (pl.P.chamfer_init_dist0 < (int32_t)LG_INIT0)   // (a zeroed struct, or a value a real distance could reach)
+        return fail(h, LG_ERR_INVALID, "chamfer_init_dist0 must be in [INT_MAX >> 2, INT_MAX] (lg_default_params: INT_MAX >> 2)");
     pl.B = B; pl.H = H; pl.W = W; pl.WW = (W + 63) / 64;
     pl.tiles_x = (W + LG_TW - 1) / LG_TW; pl.tiles_y = (H + LG_TH - 1) / LG_TH;
     if (pl.tiles_x * pl.tiles_y > 8192) return fail(h, LG_ERR_UNSUPPORTED, "image too large for the top-k tile table");

@@ -11,7 +11,7 @@
 #define LG_C5 143976u       // 2.1969
 #define LG_A3 62587u        // 0.955
 #define LG_B3 89738u        // 1.3693
-#define LG_INIT0 0x1FFFFFFFu  // INT_MAX >> 2 : OpenCV's border initialiser
+#define LG_INIT0 0x1FFFFFFFu  // INT_MAX >> 2 : OpenCV's border initialiser, the default of lg_params.chamfer_init_dist0
 #define LG_INF 0x3FFFFFFFu    // "no path yet" inside the DT sweeps (never wins against a real distance)
 #define LG_NOSRC 0x20000000u  // values >= this after the backward sweep mean: image has no source pixel
 #define LG_HCAP 16383u        // run distance of a row without any zero pixel in the image (row search; W <= 8192)
@@ -83,6 +83,7 @@ struct LgFinalArgs {
     float iso_w_close, iso_w_wide, iso_ramp_top, iso_ramp_bottom, iso_inv_max;
     float min_edge_distance, stem_valid_thresh;
     float inv_maxd;
+    uint32_t init0;    // lg_params.chamfer_init_dist0
     float inv_2s2, iso_ramp_step;   // 1 / (2 optimal_distance^2) (float32 reciprocal), (ramp_bottom - ramp_top) / (H - 1)
     float k1[7];  // separable 1-D Gaussian: 2 * gauss_r + 1 taps, sigma = size / 6 (image_processor.py:25-32)
     int gauss_r;    // radius of that Gaussian: 0..3 (lg_params.gaussian_size 1, 3, 5, 7)
@@ -111,7 +112,7 @@ void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* 
 int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
                        const LgWin* win, int B, int H, int W, int WW, hipStream_t s);
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,
-                 int H, int W, hipStream_t s);
+                 int H, int W, uint32_t init0, hipStream_t s);   // init0: lg_params.chamfer_init_dist0 (frames without a zero pixel)
 // max d_out outside the sweep windows (closed-form chamfer norm on the frame border) -> atomicMax into maxfix[b][1]
 void lg_launch_dout_border(const unsigned long long* bits, const LgWin* win, uint32_t* maxfix, int B, int H, int W, int WW,
                            hipStream_t s);

@@ -90,9 +90,13 @@ __device__ __forceinline__ uint32_t lg_wave_max_u32(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t lg_orderable(float s) {  // monotone float -> uint32 map
     if (s == 0.0f) s = 0.0f;  // -0.0 -> +0.0 (numpy sorts them as equal)
+    if (s != s) return 0xFFFFFFFFu;   // NaN of either sign: np.argsort puts NaN last, the reference's [::-1] puts it FIRST (:454)
     uint32_t b = __float_as_uint(s);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+// valid_scores = traditional_score * valid_regions (grasp_point_selector.py:451) -- a product, not a selection: a NaN or
+// infinite score (non-finite depth on the leaf) stays NaN where the pixel is not valid, and NaN leads the candidate order
+__device__ __forceinline__ float lg_valid_score(float trad, bool valid) { return trad * (valid ? 1.0f : 0.0f); }
 __device__ __forceinline__ int lg_reflect(int v, int n) {  // torch 'reflect' index, clamped for safety
     if (v < 0) v = -v;
     if (v >= n) v = 2 * (n - 1) - v;
@@ -435,7 +439,7 @@ void lg_launch_dout_border(const unsigned long long* bits, const LgWin* win, uin
 template <int T, int E, bool BWD, bool VEC>
 __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ tmp,
                                                    float* __restrict__ dist_out, uint32_t* __restrict__ maxfix,
-                                                   const LgWin* __restrict__ wins, int H, int W) {
+                                                   const LgWin* __restrict__ wins, int H, int W, uint32_t init0) {
     constexpr int NW = T / 64;
     constexpr int WC = 64 * E;                 // columns per wave
     constexpr int D = (BWD || E > 4) ? 4 : 8;  // rows per prefetch group (two groups are resident)
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
                         uint32_t val = v[k];
                         if (val >= LG_NOSRC) {  // image without any source pixel: OpenCV's border-initialised result
                             int dd = min(min(pc + 1, W - pc), min(prow + 1, H - prow));
-                            val = LG_INIT0 + (uint32_t)dd * LG_A5;
+                            val = init0 + (uint32_t)dd * LG_A5;
                         }
                         if (pc < W) mx = max(mx, val);
                         o[E - 1 - k] = (float)val * (1.0f / 65536.0f);
@@ -675,15 +679,15 @@ __global__ __launch_bounds__(T) void lg_dt5_kernel(const uint8_t* __restrict__ m
 
 template <int T, int E>
 static void lg_dt_launch_t(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
-                           const LgWin* win, int B, int H, int W, hipStream_t s) {
+                           const LgWin* win, int B, int H, int W, uint32_t init0, hipStream_t s) {
     dim3 grid(2, B), block(T);
     const bool vec = (W % E) == 0 && W >= E;
     if (bwd) {
-        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
-        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W, init0);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, true, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W, init0);
     } else {
-        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
-        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W);
+        if (vec) hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, true>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W, init0);
+        else hipLaunchKernelGGL((lg_dt5_kernel<T, E, false, false>), grid, block, 0, s, mask, tmp, dist_out, maxfix, win, H, W, init0);
     }
 }
 
@@ -706,26 +710,26 @@ int lg_dt_geometry(int W, int* waves) {
 }
 
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,
-                 int H, int W, hipStream_t s) {
+                 int H, int W, uint32_t init0, hipStream_t s) {
     // threads * E columns must cover the row.  E = 4 keeps the per-row dependency chain short (best up to
     // 2048 columns: 0.70/0.82 ms vs 0.82/0.91 ms at 1080p); at 4K 512x8 beats 1024x4 (2.04/2.54 vs 2.65/3.12 ms).
     // LG_DT_E=8 forces 8 columns per thread (experiments).
     static const int force_e = getenv("LG_DT_E") ? atoi(getenv("LG_DT_E")) : 0;
     if (force_e == 8) {
-        if (W <= 512) lg_dt_launch_t<64, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-        else if (W <= 1024) lg_dt_launch_t<128, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-        else if (W <= 2048) lg_dt_launch_t<256, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-        else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-        else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+        if (W <= 512) lg_dt_launch_t<64, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+        else if (W <= 1024) lg_dt_launch_t<128, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+        else if (W <= 2048) lg_dt_launch_t<256, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+        else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+        else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
         else return -1;
         return 0;
     }
-    if (W <= 256) lg_dt_launch_t<64, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-    else if (W <= 512) lg_dt_launch_t<128, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-    else if (W <= 1024) lg_dt_launch_t<256, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-    else if (W <= 2048) lg_dt_launch_t<512, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
-    else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);   // 4K: 8 waves beat 16 (measured)
-    else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, s);
+    if (W <= 256) lg_dt_launch_t<64, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+    else if (W <= 512) lg_dt_launch_t<128, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+    else if (W <= 1024) lg_dt_launch_t<256, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+    else if (W <= 2048) lg_dt_launch_t<512, 4>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
+    else if (W <= 4096) lg_dt_launch_t<512, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);   // 4K: 8 waves beat 16 (measured)
+    else if (W <= 8192) lg_dt_launch_t<1024, 8>(bwd, mask, tmp, dist_out, maxfix, win, B, H, W, init0, s);
     else return -1;
     return 0;
 }
@@ -1570,7 +1574,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
                     const float sdf = (ap->sdf_w_interior * interior + ap->sdf_w_align * align + ap->sdf_w_sdf * sdfn) * m;
                     // degenerate isolation map: chamfer-3 transform of an image with no zero pixel (:595-633)
                     const int dbrd = min(min(x + 1, W - x), dyb);
-                    const float dt3 = (float)(LG_INIT0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
+                    const float dt3 = (float)(ap->init0 + (uint32_t)dbrd * LG_A3) * (1.0f / 65536.0f);
                     const float s = dt3 * ap->iso_inv_max;
                     const float iso = (ap->iso_w_close * s + ap->iso_w_wide * s) * ramp * m;
                     // fusion + validity                                                      (:272-288)
@@ -1580,7 +1584,7 @@ __global__ __launch_bounds__(256) LG_FINAL_WPE_ATTR void lg_final_kernel(LgFinal
                     if (valid) vbytes |= 1u << (8 * j);
                     if (x < W) {
                         unsigned long long key =
-                            ((unsigned long long)lg_orderable(valid ? trad : 0.0f) << 32) | (uint32_t)(y * W + x);
+                            ((unsigned long long)lg_orderable(lg_valid_score(trad, valid)) << 32) | (uint32_t)(y * W + x);
                         best = key > best ? key : best;
                     }
                 }
@@ -1834,7 +1838,7 @@ __global__ __launch_bounds__(256) void lg_tilekeys_kernel(const float* __restric
         int x = bx * LG_TW + (i % LG_TW), y = by * LG_TH + (i / LG_TW);
         if (x < W && y < H) {
             size_t o = fo + (size_t)y * W + x;
-            float sc = valid[o] ? trad[o] : 0.0f;
+            float sc = lg_valid_score(trad[o], valid[o] != 0);
             unsigned long long key = ((unsigned long long)lg_orderable(sc) << 32) | (uint32_t)(y * W + x);
             best = key > best ? key : best;
         }
@@ -1955,7 +1959,7 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
                         bool dead = false;
                         for (unsigned long long m = rowrel; m; m &= m - 1) dead |= abs(x - s_cx[__builtin_ctzll(m)]) <= sup;
                         if (inside && !dead) {
-                            const unsigned long long key = ((unsigned long long)lg_orderable(vb ? sc[j] : 0.0f) << 32) | (uint32_t)(y * W + x);
+                            const unsigned long long key = ((unsigned long long)lg_orderable(lg_valid_score(sc[j], vb != 0)) << 32) | (uint32_t)(y * W + x);
                             best = key > best ? key : best;
                         }
                     }
@@ -1998,7 +2002,7 @@ __global__ __launch_bounds__(LG_TOPK_T) void lg_topk_kernel(const float* __restr
                 tt_[g] = __builtin_nontemporal_load(trad + fo + off_[g]);
             }
 #pragma unroll
-            for (int g = 0; g < GRP; g++) sc_[g] = (idx_[g] >= 0 && vv_[g]) ? tt_[g] : 0.0f;
+            for (int g = 0; g < GRP; g++) sc_[g] = idx_[g] >= 0 ? lg_valid_score(tt_[g], vv_[g] != 0) : 0.0f;
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
                 if (cb + g < chunks) {   // uniform across the workgroup

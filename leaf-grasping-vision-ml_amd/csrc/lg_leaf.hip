@@ -4,9 +4,10 @@
 //                    "pixel belongs to some leaf" (1 bit/px) and the first leaf pixel (the field's arg-min, :70)
 //   k_accumulate     labels + depth of the leaf runs: per-slot area, sum x, sum y (int64, exact), sum depth, sum ray length
 //                    (f64), border flag; every leaf pixel is appended to an unordered (slot, depth key) list (8 B per leaf pixel)
-//   k_hist x4        exact median depth (np.median, :41-47) by 4 x 8-bit radix select over THAT list (leaves cover 15-30 % of a
-//                    frame: each pass reads ~1.5 B/px instead of 6), + k_successor for even counts; LDS histograms hold 64 slots,
-//                    frames with more labels (up to 1024) run further slot groups in the grid's z dimension
+//   k_hist x3..4     exact median depth (np.median, :41-47) by 8-bit radix select over THAT list (leaves cover 15-30 % of a
+//                    frame: each pass reads ~1.5 B/px instead of 6), on keys relative to the leaf's smallest key (three passes for
+//                    a leaf whose depths span less than 2^24 float steps); the last pass also yields the successor for even
+//                    counts; LDS histograms hold 16 slots, frames with more labels (up to 1024) run further slot groups
 //   k_edt_bb         global clutter extrema (:66-71): arg-max of the exact Euclidean distance to the nearest leaf pixel, first
 //                    occurrence, by branch and bound on the bit mask -- the distance field is 1-Lipschitz, so a square cell whose
 //                    centre value + half diagonal stays below the best value found so far cannot hold the maximum.  32-px cells,
@@ -17,6 +18,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -142,18 +144,24 @@ __global__ __launch_bounds__(256) void k_presence_bits(const int16_t* __restrict
     if (threadIdx.x == 0 && s_first != ~0ull) atomicMin(first_leaf, s_first);
 }
 
-// prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1))
-__global__ void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
-    pres += (size_t)blockIdx.x * 512;  // one workgroup per frame
+// prefix popcounts of the presence words: slot(id) = pre[id>>6] + popc(pres[id>>6] & ((1<<(id&63))-1)); one wave per frame
+__global__ __launch_bounds__(64) void k_prefix(const unsigned long long* __restrict__ pres, int* __restrict__ pre, int* __restrict__ nlab) {
+    pres += (size_t)blockIdx.x * 512;
     pre += (size_t)blockIdx.x * 512;
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int w = 0; w < 512; w++) {
-            pre[w] = acc;
-            acc += __popcll(pres[w]);
-        }
-        nlab[blockIdx.x] = acc;
+    const int lane = threadIdx.x;
+    int c[8], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c[k] = __popcll(pres[8 * lane + k]); mine += c[k]; }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    int acc = incl - mine;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { pre[8 * lane + k] = acc; acc += c[k]; }
+    if (lane == 63) nlab[blockIdx.x] = incl;
 }
 
 __device__ __forceinline__ int slot_of(int id, const unsigned long long* pres, const int* pre) {
@@ -166,6 +174,7 @@ struct LeafAcc {  // device accumulators, one per slot
     long long sum_x, sum_y;
     double sum_depth, sum_ray;
     int border;
+    unsigned kmax, nkmin;   // largest depth key, ~(smallest depth key): both grow by atomicMax from the all-zero state
     int pad;
 };
 
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                                                     int H, int W, const unsigned long long* __restrict__ pres,
                                                     const int* __restrict__ pre, float cx, float cy, float f,
                                                     LeafAcc* __restrict__ acc, unsigned long long* __restrict__ comp,
-                                                    unsigned int* __restrict__ comp_n, size_t comp_stride, unsigned int segcap) {
+                                                    unsigned int* __restrict__ comp_n, size_t comp_stride, unsigned int segcap, int ablate) {
     __shared__ LeafAcc s_acc[LGL_ACC_LDS];
     __shared__ unsigned int s_cnt;                          // entries of this workgroup's list segment so far
     {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
     if (threadIdx.x == 0) s_cnt = 0;
     for (int i = threadIdx.x; i < LGL_ACC_LDS; i += 256) {
         s_acc[i].area = 0; s_acc[i].sum_x = 0; s_acc[i].sum_y = 0;
-        s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0;
+        s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0; s_acc[i].kmax = 0; s_acc[i].nkmin = 0;
     }
     __syncthreads();
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
@@ -207,34 +216,38 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
             x1 = min(x0 + LGL_RUN, W);
             any = load_run(lab, W, y, x0, x1, vec, ids);
         }
-        int cnt = 0;
+        if (__ballot(any) == 0ull) continue;                 // wave-uniform: no leaf pixel in these 1024 pixels
         if (any) {
             load_run_depth(depth, W, y, x0, x1, vec, dv);
+        } else {
 #pragma unroll
-            for (int k = 0; k < LGL_RUN; k++) cnt += ids[k] > 0;
+            for (int k = 0; k < LGL_RUN; k++) ids[k] = 0;
         }
-        // list positions: exclusive prefix of the lanes' counts + one atomic per wave (the list is unordered: a median only
-        // needs the multiset)
-        int incl = cnt;
+        // List positions (the list is unordered: a median only needs the multiset).  Pixel k of every lane is written by ONE store
+        // instruction whose active lanes take consecutive entries (ballot + prefix popcount): 512 contiguous bytes per
+        // instruction.  (Each lane writing its own 16 entries back to back made every one of the 16 stores touch 64 different
+        // cache lines: 0.30 of the kernel's 0.77 ms per 128 frames.)  One LDS atomic per wave reserves the space.
+        unsigned long long bal[LGL_RUN];
+        unsigned total = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
+        for (int k = 0; k < LGL_RUN; k++) {
+            bal[k] = __ballot(ids[k] > 0);
+            total += (unsigned)__popcll(bal[k]);
         }
-        const int total = __shfl(incl, 63, 64);
-        if (total == 0) continue;                            // wave-uniform: no leaf pixel in these 1024 pixels
         unsigned base = 0;
-        if (lane == 63) base = atomicAdd(&s_cnt, (unsigned)total);
-        base = __shfl(base, 63, 64);
-        if (!any) continue;
-        unsigned long long* dst = comp + base + (incl - cnt);
+        if (lane == 0) base = atomicAdd(&s_cnt, total);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes below this one
         int cur = 0, cur_slot = 0;
         unsigned long long a = 0; long long sx = 0; double sd = 0.0, sr = 0.0; int bd = 0;
+        unsigned kmx = 0, nkmn = 0;
         const double dy = (double)y - (double)cy;
         auto flush = [&]() {
-            if (cur > 0 && a) {
+            if (cur > 0 && a && !(ablate & 2)) {
                 const int s = cur_slot;
                 if (s < LGL_ACC_LDS) {
+                    if (kmx > s_acc[s].kmax) atomicMax(&s_acc[s].kmax, kmx);      // (plain pre-test: a leaf's range is set by few runs)
+                    if (nkmn > s_acc[s].nkmin) atomicMax(&s_acc[s].nkmin, nkmn);
                     atomicAdd(&s_acc[s].area, a);
                     atomicAdd((unsigned long long*)&s_acc[s].sum_x, (unsigned long long)sx);
                     atomicAdd((unsigned long long*)&s_acc[s].sum_y, (unsigned long long)((long long)a * y));
@@ -242,6 +255,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                     atomicAdd(&s_acc[s].sum_ray, sr);
                     if (bd) atomicOr(&s_acc[s].border, 1);
                 } else if (s < LGL_MAXL) {
+                    atomicMax(&acc[s].kmax, kmx);
+                    atomicMax(&acc[s].nkmin, nkmn);
                     atomicAdd(&acc[s].area, a);
                     atomicAdd((unsigned long long*)&acc[s].sum_x, (unsigned long long)sx);
                     atomicAdd((unsigned long long*)&acc[s].sum_y, (unsigned long long)((long long)a * y));
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
             if (id < 0) id = 0;
             if (id != cur) {
                 flush();
-                cur = id; a = 0; sx = 0; sd = 0.0; sr = 0.0; bd = 0;
+                cur = id; a = 0; sx = 0; sd = 0.0; sr = 0.0; bd = 0; kmx = 0; nkmn = 0;
                 if (id > 0) cur_slot = slot_of(id, pres, pre);
             }
             if (id > 0) {
@@ -271,10 +286,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                 const double v = dx * dx + dy * dy + f2;
                 const float r0 = __builtin_amdgcn_sqrtf((float)v);
                 const double rd = (double)r0;
-                sr += rd + (v - rd * rd) * (double)(0.5f * __frcp_rn(r0));
+                if (!(ablate & 4)) sr += rd + (v - rd * rd) * (double)(0.5f * __frcp_rn(r0));
                 bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
-                *dst++ = ((unsigned long long)(unsigned)cur_slot << 32) | f2key(dv[k]);
+                const unsigned key = f2key(dv[k]);
+                kmx = max(kmx, key); nkmn = max(nkmn, ~key);
+                if (!(ablate & 1)) comp[base + (unsigned)__popcll(bal[k] & lt)] = ((unsigned long long)(unsigned)cur_slot << 32) | key;
             }
+            base += (unsigned)__popcll(bal[k]);
         }
         flush();
     }
@@ -287,60 +305,82 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
             atomicAdd(&acc[i].sum_depth, s_acc[i].sum_depth);
             atomicAdd(&acc[i].sum_ray, s_acc[i].sum_ray);
             if (s_acc[i].border) atomicOr(&acc[i].border, 1);
+            atomicMax(&acc[i].kmax, s_acc[i].kmax);
+            atomicMax(&acc[i].nkmin, s_acc[i].nkmin);
         }
     }
     if (threadIdx.x == 0) *comp_n = s_cnt;
 }
 
 // ---------------------------------------------------------------- radix select (median) over the (slot, key) list
+// Keys are taken RELATIVE to the leaf's smallest key (k_accumulate delivers min and max): a leaf's depths span a fraction of a
+// metre, i.e. ~2^22 float32 steps, so the most significant byte of (key - min) is 0 for every pixel and that pass has nothing
+// to decide -- three passes over the list instead of four (four for a leaf whose depths span more than 2^24 steps, fewer for a
+// flat one).  A slot takes part in pass p only while p < npass; a frame none of whose slots needs a pass leaves it at once.
 struct SelState {       // per slot
-    uint32_t prefix;    // key bits fixed so far (high bits)
+    uint32_t prefix;    // bits of (key - base) fixed so far (high bits)
     uint32_t rank;      // remaining 0-based rank inside the current prefix bucket
     uint32_t n_le;      // (after the last pass) number of elements equal to the key ranked ABOVE the selected one
     uint32_t key;       // selected key (after the last pass)
+    uint32_t base;      // smallest key of the slot
+    uint32_t npass;     // 8-bit digits of (largest key - base) that can differ: 0 .. 4
 };
 
-// median ranks from the per-slot areas (lower median index); grid (LGL_MAXL / 256, B)
-__global__ void k_seed(const LeafAcc* __restrict__ acc, SelState* __restrict__ st) {
+// median ranks from the per-slot areas (lower median index), key range -> passes; grid (LGL_MAXL / 256, B)
+__global__ void k_seed(const LeafAcc* __restrict__ acc, SelState* __restrict__ st, int* __restrict__ maxpass) {
     const size_t fr = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= LGL_MAXL) return;
-    const unsigned long long a = acc[fr * LGL_MAXL + i].area;
+    const LeafAcc& A = acc[fr * LGL_MAXL + i];
+    const unsigned long long a = A.area;
     SelState z;
-    z.prefix = 0; z.key = 0; z.n_le = 0;
+    z.prefix = 0; z.n_le = 0;
     z.rank = a ? (uint32_t)((a - 1) / 2) : 0;
+    z.base = a ? ~A.nkmin : 0u;
+    const uint32_t range = a ? A.kmax - z.base : 0u;
+    z.npass = range ? (uint32_t)(32 - __builtin_clz(range) + 7) / 8u : 0u;
+    z.key = z.base;                                     // npass == 0: every element equals the smallest key
+    if (z.npass == 0 && a) z.n_le = (uint32_t)(a - 1) - z.rank;
     st[fr * LGL_MAXL + i] = z;
+    if (z.npass) atomicMax(&maxpass[fr], (int)z.npass);
 }
 
-// histogram of digit `pass` (3 = most significant byte) among the list entries of slot group blockIdx.z whose higher bytes
-// match their slot's prefix
+// histogram of digit `pass` (3 = most significant byte) of (key - base) among the list entries of one slot group whose
+// higher bytes match their slot's prefix.  GROUP slots share the LDS histogram (16: 16 KB, eight workgroups per CU -- the pass
+// is bound by the list's load latency, not by the LDS atomics: with 64 slots = 64 KB two workgroups fit and a pass took 0.17 ms
+// per 128 frames whether the atomics ran or not); frames with more labels run further slot groups.  The last pass (0) also
+// finds, per slot, the smallest relative key ABOVE the selected key's 256-key bucket (successor for even counts, when the
+// bucket itself holds nothing above the selected key).
+template <int GROUP>
 __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restrict__ comp, const unsigned int* __restrict__ comp_n,
                                               size_t comp_stride, unsigned int segcap, const int* __restrict__ nlab,
-                                              const SelState* __restrict__ st, int pass, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_h[LGL_GROUP * 256];
-    __shared__ uint32_t s_prefix[LGL_GROUP];
+                                              const SelState* __restrict__ st, const int* __restrict__ maxpass, int pass,
+                                              uint32_t* __restrict__ hist, uint32_t* __restrict__ above, int ablate) {
+    __shared__ uint32_t s_h[GROUP * 256];
+    __shared__ uint32_t s_prefix[GROUP], s_base[GROUP], s_np[GROUP], s_above[GROUP];
     const size_t fr = blockIdx.y;
+    if (pass >= maxpass[fr]) return;                          // no slot of this frame needs the pass (whole workgroup)
     comp += fr * comp_stride + (size_t)blockIdx.x * segcap;   // workgroup x reads the segment k_accumulate's workgroup x wrote
     const unsigned n = comp_n[fr * gridDim.x + blockIdx.x];
     const int nl = min(nlab[fr], LGL_MAXL);
     const int shift = 8 * pass;
     const uint32_t himask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
     const int lane = threadIdx.x & 63;
-    // slot groups of 64 (the LDS histogram's size); a frame has one unless it carries more than 64 labels
-    for (int g = 0; g * LGL_GROUP < nl; g++) {
-        const int nsl = min(LGL_GROUP, nl - g * LGL_GROUP);
-        const SelState* stg = st + fr * LGL_MAXL + g * LGL_GROUP;
-        uint32_t* histg = hist + (fr * LGL_MAXL + (size_t)g * LGL_GROUP) * 256;
+    for (int g = 0; g * GROUP < nl; g++) {
+        const int nsl = min(GROUP, nl - g * GROUP);
+        const SelState* stg = st + fr * LGL_MAXL + g * GROUP;
+        uint32_t* histg = hist + (fr * LGL_MAXL + (size_t)g * GROUP) * 256;
         __syncthreads();
         for (int i = threadIdx.x; i < nsl * 256; i += 256) s_h[i] = 0;
-        if (threadIdx.x < nsl) s_prefix[threadIdx.x] = stg[threadIdx.x].prefix;
+        if (threadIdx.x < nsl) {
+            const SelState z = stg[threadIdx.x];
+            s_prefix[threadIdx.x] = z.prefix; s_base[threadIdx.x] = z.base; s_np[threadIdx.x] = z.npass;
+            s_above[threadIdx.x] = 0xFFFFFFFFu;
+        }
         __syncthreads();
-        // One entry per lane and load (512 contiguous bytes per wave instruction).  The pixels of a run sit next to each other
-        // in the list and the depths of a leaf share their high bytes, so neighbouring lanes mostly hit the SAME (slot, bin):
-        // each maximal group of equal neighbours inside the wave becomes one LDS atomic of its first lane (ballot of the heads).
-        // Four loads per thread in flight: with 64 KB of LDS per workgroup two workgroups (two waves per SIMD) share a CU, and one
-        // load -> wait -> count round per 256 entries left the pass bound by the list's load latency (0.33 ms for 0.34 GB; the
-        // successor pass reads the same list in 0.09 ms).
+        // One entry per lane and load (512 contiguous bytes per wave instruction), four loads per thread in flight.  Neighbouring
+        // entries mostly belong to the same slot and, in the upper digits, to the same bin: each maximal group of equal
+        // neighbours inside the wave becomes one LDS atomic of its first lane (ballot of the heads).
         constexpr int UNR = 4;
         for (unsigned i0 = 0; i0 < n; i0 += 256 * UNR) {
             unsigned long long e_[UNR];
@@ -354,14 +394,17 @@ __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restri
                 int idx = -1;
                 if (i0 + k * 256 + threadIdx.x < n) {
                     const unsigned long long e = e_[k];
-                    const int slot = (int)(e >> 32) - g * LGL_GROUP;
-                    const uint32_t key = (uint32_t)e;
-                    if ((unsigned)slot < (unsigned)nsl && (key & himask) == (s_prefix[slot] & himask)) idx = slot * 256 + (int)((key >> shift) & 0xFFu);
+                    const int slot = (int)(e >> 32) - g * GROUP;
+                    if ((unsigned)slot < (unsigned)nsl && (uint32_t)pass < s_np[slot]) {
+                        const uint32_t rel = (uint32_t)e - s_base[slot], pf = s_prefix[slot];
+                        if ((rel & himask) == (pf & himask)) idx = slot * 256 + (int)((rel >> shift) & 0xFFu);
+                        else if (pass == 0 && rel > pf && rel < s_above[slot]) atomicMin(&s_above[slot], rel);   // (rel > pf: a higher bucket)
+                    }
                 }
                 const int prev = __shfl_up(idx, 1, 64);
                 const bool head = lane == 0 || idx != prev;
                 const unsigned long long hm = __ballot(head);
-                if (head && idx >= 0) {
+                if (head && idx >= 0 && !(ablate & 8)) {
                     const unsigned long long later = lane == 63 ? 0ull : (hm >> (lane + 1));
                     const int len = later ? __builtin_ctzll(later) + 1 : 64 - lane;
                     atomicAdd(&s_h[idx], (uint32_t)len);
@@ -371,110 +414,118 @@ __global__ __launch_bounds__(256) void k_hist(const unsigned long long* __restri
         __syncthreads();
         for (int i = threadIdx.x; i < nsl * 256; i += 256)
             if (s_h[i]) atomicAdd(&histg[i], s_h[i]);
+        if (pass == 0 && threadIdx.x < nsl && s_above[threadIdx.x] != 0xFFFFFFFFu)
+            atomicMin(&above[fr * LGL_MAXL + g * GROUP + threadIdx.x], s_above[threadIdx.x]);
     }
 }
 
-// pick the bin holding the wanted rank, descend; one thread per slot; grid (LGL_MAXL / 64, B)
-__global__ void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, const int* __restrict__ nlab, int pass) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nlab[blockIdx.y] || s >= LGL_MAXL) return;
-    st += (size_t)blockIdx.y * LGL_MAXL;
-    hist += (size_t)blockIdx.y * LGL_MAXL * 256;
-    uint32_t* h = hist + (size_t)s * 256;
-    uint32_t rank = st[s].rank, accum = 0;
-    int bin = 255;
-    for (int b = 0; b < 256; b++) {
-        uint32_t c = h[b];
-        if (rank < accum + c) { bin = b; break; }
-        accum += c;
-    }
-    uint32_t inbin = h[bin];
-    st[s].prefix |= ((uint32_t)bin) << (8 * pass);
-    st[s].rank = rank - accum;
-    if (pass == 0) {
-        st[s].key = st[s].prefix;
-        st[s].n_le = inbin - (rank - accum) - 1;  // elements equal to the key ranked ABOVE the selected one
-    }
-    for (int b = 0; b < 256; b++) h[b] = 0;  // the histogram workspace is left clean: no memset per call
-}
-
-// smallest key strictly greater than the selected key, per slot (upper median for even counts); all slots in one pass
-__global__ __launch_bounds__(256) void k_successor(const unsigned long long* __restrict__ comp, const unsigned int* __restrict__ comp_n,
-                                                   size_t comp_stride, unsigned int segcap, const int* __restrict__ nlab,
-                                                   const SelState* __restrict__ st, uint32_t* __restrict__ succ) {
-    __shared__ uint32_t s_key[LGL_MAXL], s_min[LGL_MAXL];
+// pick the bin holding the wanted rank, descend; one WAVE per slot (lane = four bins, wave prefix sum); grid (16, B).
+// Pass 0 finishes the slot: selected key, how many equal elements rank above it, and the successor key (smallest key above
+// the selected one: the next non-empty bin of the same bucket, else what k_hist found above the bucket) into succ.
+__global__ __launch_bounds__(256) void k_select(SelState* __restrict__ st, uint32_t* __restrict__ hist, const int* __restrict__ nlab,
+                                                const int* __restrict__ maxpass, int pass, const uint32_t* __restrict__ above,
+                                                uint32_t* __restrict__ succ) {
     const size_t fr = blockIdx.y;
-    comp += fr * comp_stride + (size_t)blockIdx.x * segcap; st += fr * LGL_MAXL; succ += fr * LGL_MAXL;
-    const unsigned n = comp_n[fr * gridDim.x + blockIdx.x];
+    if (pass >= maxpass[fr]) return;
     const int nl = min(nlab[fr], LGL_MAXL);
-    for (int i = threadIdx.x; i < nl; i += 256) { s_key[i] = st[i].key; s_min[i] = 0xFFFFFFFFu; }
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < n; i += 256) {
-        const unsigned long long e = comp[i];
-        const int s = (int)(e >> 32);
-        const uint32_t key = (uint32_t)e;
-        if (s < nl && key > s_key[s] && key < s_min[s]) atomicMin(&s_min[s], key);   // (plain pre-test: most elements fail it)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    st += fr * LGL_MAXL; hist += fr * LGL_MAXL * 256; above += fr * LGL_MAXL; succ += fr * LGL_MAXL;
+    for (int s = blockIdx.x * 4 + wave; s < nl; s += gridDim.x * 4) {
+        SelState z = st[s];
+        if ((uint32_t)pass >= z.npass) continue;              // (wave-uniform)
+        uint4* h4 = reinterpret_cast<uint4*>(hist + (size_t)s * 256) + lane;
+        const uint4 c = *h4;
+        *h4 = make_uint4(0u, 0u, 0u, 0u);                     // the histogram workspace is left clean: no memset per call
+        const uint32_t mine = c.x + c.y + c.z + c.w;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t excl = incl - mine, rank = z.rank;
+        const bool here = rank >= excl && rank < incl;        // exactly one lane (the counts add up to more than the rank)
+        int bin = -1; uint32_t accum = 0, inbin = 0;
+        if (here) {
+            const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+            uint32_t acc2 = excl;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (bin < 0 && rank < acc2 + cc[q]) { bin = 4 * lane + q; accum = acc2; inbin = cc[q]; }
+                acc2 += cc[q];
+            }
+        }
+        const unsigned long long who = __ballot(here);
+        const int src = who ? __builtin_ctzll(who) : 0;
+        bin = __shfl(bin, src, 64); accum = __shfl(accum, src, 64); inbin = __shfl(inbin, src, 64);
+        if (bin < 0) bin = 255;                               // (unreachable: kept from the serial form)
+        z.prefix |= ((uint32_t)bin) << (8 * pass);
+        z.rank = rank - accum;
+        if (pass == 0) {
+            z.key = z.base + z.prefix;
+            z.n_le = inbin - z.rank - 1;                      // elements equal to the key ranked ABOVE the selected one
+            // successor: the first non-empty bin above `bin` in this bucket, else the smallest key above the bucket
+            const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+            int nb = 256;
+#pragma unroll
+            for (int q = 3; q >= 0; q--)
+                if (cc[q] && 4 * lane + q > bin) nb = 4 * lane + q;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) nb = min(nb, __shfl_xor(nb, o, 64));
+            if (lane == 0) {
+                const uint32_t ab = above[s];
+                succ[s] = nb < 256 ? z.base + ((z.prefix & ~0xFFu) | (uint32_t)nb) : (ab != 0xFFFFFFFFu ? z.base + ab : 0xFFFFFFFFu);
+            }
+        }
+        if (lane == 0) st[s] = z;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nl; i += 256)
-        if (s_min[i] != 0xFFFFFFFFu) atomicMin(&succ[i], s_min[i]);
 }
 
 // ---------------------------------------------------------------- exact EDT arg-max by branch and bound on the bit mask
-// Exact squared distance from (y, x) to the nearest set bit, given that it is <= ub2 (0xFFFFFFFF when nothing is known).
+// ---- word occupancy of the bit rows: occ[y] bit i = word i of row y holds a leaf pixel (W <= 4096: a row is at most 64 words).
+// With it the leaf pixel of a row nearest to column x is found with ONE more round trip -- the own word and the nearest
+// non-empty word on either side, all three requested together -- instead of a walk over the row's words outwards from x (up
+// to WW dependent loads per row for a point far from every leaf, which is exactly where the arg-max search spends its
+// evaluations: 1.16 -> 0.45 ms per 128 frames).  One wave per row.
+__global__ __launch_bounds__(256) void k_rowocc(const unsigned long long* __restrict__ bits, int H, int WW,
+                                                unsigned long long* __restrict__ occ) {
+    const size_t fr = blockIdx.y;
+    bits += fr * H * WW; occ += fr * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int y = blockIdx.x * 4 + wave; y < H; y += gridDim.x * 4) {
+        const unsigned long long z = lane < WW ? bits[(size_t)y * WW + lane] : 0ull;
+        const unsigned long long nz = __ballot(z != 0ull);
+        if (lane == 0) occ[y] = nz;
+    }
+}
+
+// Exact squared distance from (y, x) to the nearest leaf pixel, given that it is <= ub2 (0xFFFFFFFF when nothing is known).
 // One WAVE per point: the 64 lanes take 64 rows at a time (first the 64 rows around y, then 64 more above and 64 more below,
-// ...), each lane finds the set bit of its row nearest to x that could still beat the best value, a wave minimum closes
-// the round.  All lanes return the same value.  (One thread per point made every step a dependent L2 round trip: 30 ms per
-// frame.)
-// lo2: every pixel closer than sqrt(lo2) is known to be background (a parent cell's value minus the centres' distance): the
-//      words of a row that lie inside that disk are not read.  need2: the caller only cares about values >= need2 (a cell
-//      whose bound cannot reach the best value is dropped whatever its exact value): the search stops once it is below.
-__device__ inline uint32_t edt_point_wave(const unsigned long long* __restrict__ bits, int H, int W, int WW, int y, int x,
-                                          uint32_t ub2, uint32_t lo2, uint32_t need2, int lane) {
+// ...), each lane finds the leaf pixel of its row nearest to x, a wave minimum closes the round.  All lanes return the same
+// value.  need2: the caller only cares about values >= need2 (a cell whose bound cannot reach the best value is dropped
+// whatever its exact value): the search stops once it is below.
+__device__ inline uint32_t edt_point_wave_occ(const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ occ,
+                                              int H, int W, int WW, int y, int x, uint32_t ub2, uint32_t need2, int lane) {
     unsigned long long best = (unsigned long long)ub2 + 1ull;   // search for d2 < best
     const int w0 = x >> 6, b = x & 63;
-    auto row_probe = [&](int yy) -> unsigned long long {        // best d2 of row yy below `best`, or ~0
+    auto row_probe = [&](int yy) -> unsigned long long {        // d2 of row yy's nearest leaf pixel, or ~0
         if (yy < 0 || yy >= H) return ~0ull;
         const long long dyl = (long long)yy - y;
         const unsigned long long dy2 = (unsigned long long)(dyl * dyl);
         if (dy2 >= best) return ~0ull;
+        const unsigned long long oc = occ[yy];
+        if (!oc) return ~0ull;
         const unsigned long long* row = bits + (size_t)yy * WW;
-        unsigned long long lim = best - dy2;                    // need dx^2 < lim
-        // known-empty disk: in this row no set bit has |dx| < dxe
-        long long dxe = 0;
-        if ((unsigned long long)lo2 > dy2) dxe = (long long)sqrt((double)((unsigned long long)lo2 - dy2));   // floor: conservative
+        const unsigned long long lm = w0 ? oc & ((1ull << w0) - 1ull) : 0ull, rm = w0 < 63 ? oc >> (w0 + 1) : 0ull;
+        const int kl = lm ? 63 - __builtin_clzll(lm) : w0, kr = rm ? w0 + 1 + __builtin_ctzll(rm) : w0;
+        const unsigned long long wc = row[w0], wl = row[kl], wr = row[kr];   // one round trip for the three
         long long dl = -1, dr = -1;
-        int kl = 1, kr = 1;                                     // first neighbour word worth reading on each side
-        if (dxe > (b > 63 - b ? b : 63 - b)) {                  // the centre word lies inside the empty disk
-            // word w0 - k spans dx in [b + 1 + 64 (k - 1), b + 64 k], word w0 + k spans [64 k - b, 64 k + 63 - b]: a word whose
-            // farthest bit is still inside the disk holds no set bit
-            const long long nl_ = dxe - b, nr_ = dxe - 63 + b;
-            kl = nl_ <= 64 ? 1 : (int)((nl_ + 63) / 64);
-            kr = nr_ <= 64 ? 1 : (int)((nr_ + 63) / 64);
-        } else {
-            const unsigned long long wc = row[w0];
-            const unsigned long long ml = wc & (b == 63 ? ~0ull : ((2ull << b) - 1ull));   // bits <= b
-            const unsigned long long mr = wc & (~0ull << b);                               // bits >= b
-            if (ml) dl = b - (63 - __builtin_clzll(ml));
-            if (mr) dr = __builtin_ctzll(mr) - b;
-            if (dl >= 0) lim = min(lim, (unsigned long long)(dl * dl) + 1ull);
-            if (dr >= 0) lim = min(lim, (unsigned long long)(dr * dr) + 1ull);
-        }
-        for (int k = min(kl, kr); (dl < 0 || dr < 0); k++) {
-            const long long minl = (long long)b + 1 + 64ll * (k - 1), minr = 64ll * k - b;   // smallest dx of a hit in word w0 -/+ k
-            const bool canl = dl < 0 && k >= kl && w0 - k >= 0 && (unsigned long long)(minl * minl) < lim;
-            const bool canr = dr < 0 && k >= kr && w0 + k < WW && (unsigned long long)(minr * minr) < lim;
-            if (!canl && !canr && ((dl < 0 && k < kl) || (dr < 0 && k < kr))) continue;   // still inside the empty disk on one side
-            if (!canl && !canr) break;
-            if (canl) {
-                const unsigned long long w = row[w0 - k];
-                if (w) { dl = x - ((w0 - k) * 64 + (63 - __builtin_clzll(w))); lim = min(lim, (unsigned long long)(dl * dl) + 1ull); }
-            }
-            if (canr) {
-                const unsigned long long w = row[w0 + k];
-                if (w) { dr = (w0 + k) * 64 + __builtin_ctzll(w) - x; lim = min(lim, (unsigned long long)(dr * dr) + 1ull); }
-            }
-        }
+        const unsigned long long ml = wc & (b == 63 ? ~0ull : ((2ull << b) - 1ull));   // bits <= b
+        const unsigned long long mr = wc & (~0ull << b);                               // bits >= b
+        if (ml) dl = b - (63 - __builtin_clzll(ml));
+        else if (lm) dl = x - (kl * 64 + (63 - __builtin_clzll(wl)));
+        if (mr) dr = __builtin_ctzll(mr) - b;
+        else if (rm) dr = kr * 64 + __builtin_ctzll(wr) - x;
         long long dx = -1;
         if (dl >= 0) dx = dl;
         if (dr >= 0 && (dx < 0 || dr < dx)) dx = dr;
@@ -509,15 +560,15 @@ __device__ inline uint32_t edt_point_wave(const unsigned long long* __restrict__
 // index) of the first farthest background pixel, 0 when the frame has no leaf pixel or no background pixel; flag = 1 when a
 // survivor list overflowed (the caller runs the fallback)
 #define LGL_BB_T 1024
-__global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* __restrict__ bits, int H, int W, int WW,
-                                                     unsigned long long* __restrict__ qa, unsigned long long* __restrict__ qb,
+__global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* __restrict__ bits, const unsigned long long* __restrict__ occ,
+                                                     int H, int W, int WW, unsigned long long* __restrict__ qa, unsigned long long* __restrict__ qb,
                                                      unsigned long long* __restrict__ out, int* __restrict__ flag) {
     __shared__ unsigned int s_lb2, s_na, s_nb, s_any, s_ovf;
     __shared__ unsigned long long s_res;
     const int fr = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int NW = LGL_BB_T / 64;
-    bits += (size_t)fr * H * WW;
+    bits += (size_t)fr * H * WW; occ += (size_t)fr * H;
     qa += (size_t)fr * LGL_QCAP; qb += (size_t)fr * LGL_QCAP;
     if (t == 0) { s_lb2 = 0; s_na = 0; s_nb = 0; s_any = 0; s_ovf = 0; s_res = 0; }
     __syncthreads();
@@ -547,15 +598,11 @@ __global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* _
     for (int c = t; c < ny * nx; c += LGL_BB_T) {
         const int y0 = (c / nx) * S, x0 = (c % nx) * S;
         const int y1 = min(y0 + S, H), x1 = min(x0 + S, W);
+        // (S is a multiple of 64: a cell covers whole words, and the rows' word-occupancy masks answer for them)
+        const int wq0 = x0 >> 6, nwq = ((x1 - 1) >> 6) - wq0 + 1;
+        const unsigned long long wm = (nwq >= 64 ? ~0ull : ((1ull << nwq) - 1ull)) << wq0;
         unsigned long long any = 0;
-        for (int yy = y0; yy < y1 && !any; yy++)
-            for (int wq = x0 >> 6; wq <= (x1 - 1) >> 6; wq++) {
-                unsigned long long wv = bits[(size_t)yy * WW + wq];
-                const int lo_b = max(x0 - wq * 64, 0), hi_b = min(x1 - wq * 64, 64);          // bit range of the cell inside the word
-                wv >>= lo_b;
-                if (hi_b - lo_b < 64) wv &= (1ull << (hi_b - lo_b)) - 1ull;
-                any |= wv;
-            }
+        for (int yy = y0; yy < y1; yy++) any |= occ[yy] & wm;
         s_occ[c] = any != 0;
     }
     __syncthreads();
@@ -590,7 +637,7 @@ __global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* _
             }
             uint32_t d2;
             if (round && sqrt((double)ub2) + rad + 1e-6 < sqrt((double)s_lb2)) d2 = ub2;   // cannot reach the best value: not evaluated
-            else d2 = edt_point_wave(bits, H, W, WW, cy, cx, ub2, 0u, round ? need_of(rad) : 0u, lane);
+            else d2 = edt_point_wave_occ(bits, occ, H, W, WW, cy, cx, ub2, round ? need_of(rad) : 0u, lane);
             if (lane == 0) {
                 if (!(round && d2 == ub2 && sqrt((double)ub2) + rad + 1e-6 < sqrt((double)s_lb2))) atomicMax(&s_lb2, d2);
                 qb[c] = ((unsigned long long)d2 << 32) | ((unsigned long long)y0 << 16) | (unsigned long long)x0;
@@ -649,7 +696,8 @@ __global__ __launch_bounds__(LGL_BB_T) void k_edt_bb(const unsigned long long* _
             const double ub2d = ceil(ubd * ubd);
             const uint32_t ub2 = ub2d >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)ub2d;
             const uint32_t lo2 = lod <= 1.0 ? 0u : (uint32_t)floor((lod - 1e-6) * (lod - 1e-6));
-            const uint32_t d2 = edt_point_wave(bits, H, W, WW, cy, cx, ub2, lo2, need_of(rad), lane);
+            (void)lo2;
+            const uint32_t d2 = edt_point_wave_occ(bits, occ, H, W, WW, cy, cx, ub2, need_of(rad), lane);
             if (lane == 0) {
                 atomicMax(&s_lb2, d2);
                 const unsigned p = atomicAdd(&s_nb, 1u);
@@ -876,13 +924,17 @@ struct LgLeafWs {   // every array holds capB frames back to back
     unsigned long long* first_leaf;  // 1
     SelState* st;              // MAXL
     uint32_t* hist;            // MAXL*256, kept all-zero between calls (k_select clears what k_hist fills)
-    uint32_t* succ;            // MAXL
+    uint32_t* succ;            // MAXL  successor keys (k_select, last pass)
+    uint32_t* above;           // MAXL  smallest relative key above the selected key's bucket (k_hist, last pass)
+    int* maxpass;              // 1     radix passes the frame needs (k_seed)
     unsigned long long* best;  // 1
     int* bbflag;               // 1
     unsigned int* comp_n;      // 256 (one per k_accumulate workgroup)
     unsigned long long *qa, *qb;  // LGL_QCAP each
     unsigned long long* bits;  // H * ceil(W/64)
     unsigned long long* comp;  // H*W  (slot, key) list of the leaf pixels
+    unsigned long long* occ;   // H     word occupancy of the bit rows (k_rowocc)
+    size_t occ_cap;
     uint16_t* g;               // H*W   (fallback only, allocated on first use)
     unsigned long long* rowbest;  // H  (fallback only)
     lg_leaf_stat* d_out;       // [capB][out_cap] results in their final form (device) ...
@@ -897,8 +949,8 @@ struct LgLeafWs {   // every array holds capB frames back to back
 
 void lg_leaf_free(LgLeafWs*& w) {
     if (!w) return;
-    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->best, w->bbflag, w->comp_n,
-                  w->qa, w->qb, w->bits, w->comp, w->g, w->rowbest, w->d_out, w->d_hdr};
+    void* ps[] = {w->pres, w->pre, w->nlab, w->acc, w->first_leaf, w->st, w->hist, w->succ, w->above, w->maxpass, w->best, w->bbflag, w->comp_n,
+                  w->qa, w->qb, w->bits, w->comp, w->g, w->rowbest, w->d_out, w->d_hdr, w->occ};
     for (void* p : ps)
         if (p) hipFree(p);
     if (w->h_out) hipHostFree(w->h_out);
@@ -919,6 +971,7 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
             hipMalloc((void**)&w->nlab, nb * 4) || hipMalloc((void**)&w->acc, nb * sizeof(LeafAcc) * LGL_MAXL) ||
             hipMalloc((void**)&w->first_leaf, nb * 8) || hipMalloc((void**)&w->st, nb * sizeof(SelState) * LGL_MAXL) ||
             hipMalloc((void**)&w->hist, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->succ, nb * 4 * LGL_MAXL) ||
+            hipMalloc((void**)&w->above, nb * 4 * LGL_MAXL) || hipMalloc((void**)&w->maxpass, nb * 4) ||
             hipMalloc((void**)&w->best, nb * 8) || hipMalloc((void**)&w->bbflag, nb * 4) || hipMalloc((void**)&w->comp_n, nb * 4 * 256) ||
             hipMalloc((void**)&w->qa, nb * 8 * LGL_QCAP) || hipMalloc((void**)&w->qb, nb * 8 * LGL_QCAP) ||
             hipMemset(w->hist, 0, nb * 4 * LGL_MAXL * 256) || hipMalloc((void**)&w->d_hdr, nb * sizeof(LeafHdr)) ||
@@ -937,6 +990,13 @@ static int leaf_ws(LgLeafWs*& w, int B, int H, int W) {
         w->bits_cap = 0;
         if (hipMalloc((void**)&w->bits, need_words * 8)) return LG_ERR_NOMEM;
         w->bits_cap = need_words;
+    }
+    if ((size_t)w->capB * H > w->occ_cap) {
+        if (w->occ) hipFree(w->occ);
+        w->occ = nullptr;
+        w->occ_cap = 0;
+        if (hipMalloc((void**)&w->occ, (size_t)w->capB * H * 8)) return LG_ERR_NOMEM;
+        w->occ_cap = (size_t)w->capB * H;
     }
     if (need > w->px_cap) {
         if (w->comp) hipFree(w->comp);
@@ -985,16 +1045,19 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     const int WW = (W + 63) / 64;
     // streaming passes: grid-stride workgroups per frame; fewer per frame for large batches (every workgroup ends with a
     // flush of its LDS accumulators / 64 KB histogram into global atomics)
-    const int gx = std::max(16, std::min(256, 2048 / B));
+    static const int gx_budget = getenv("LG_LEAF_GX") ? atoi(getenv("LG_LEAF_GX")) : 2048;   // workgroups per batch of the streaming passes
+    const int gx = std::max(16, std::min(256, gx_budget / B));
     const dim3 grid(gx, B);
     // list segments: workgroup x of a frame meets at most ceil(runs / (gx * 256)) steps of 256 runs of 16 pixels
     const long long nruns_acc = (long long)H * ((W + LGL_RUN - 1) / LGL_RUN);
     const unsigned segcap = (unsigned)((nruns_acc + (long long)gx * 256 - 1) / ((long long)gx * 256)) * 256u * LGL_RUN;
     const size_t comp_stride = (size_t)segcap * gx;          // <= H * W + gx * 4096 entries per frame
+    static const int ablate = getenv("LG_LEAF_ABLATE") ? atoi(getenv("LG_LEAF_ABLATE")) : 0;   // timing experiments only (wrong results)
     hipMemsetAsync(w->pres, 0, nb * 512 * 8, s);
     hipMemsetAsync(w->acc, 0, nb * sizeof(LeafAcc) * LGL_MAXL, s);
     hipMemsetAsync(w->first_leaf, 0xFF, nb * 8, s);
-    hipMemsetAsync(w->succ, 0xFF, nb * 4 * LGL_MAXL, s);
+    hipMemsetAsync(w->above, 0xFF, nb * 4 * LGL_MAXL, s);
+    hipMemsetAsync(w->maxpass, 0, nb * 4, s);
     hipLaunchKernelGGL(k_presence_bits, grid, dim3(256), 0, s, labels, depth, H, W, WW, w->pres, w->bits, w->first_leaf);
     // clutter extrema: needs only the bit mask; runs beside the statistics chain on a second stream of the handle
     // (side = one of the handle's own streams: a stream more per process changes how ROCm maps streams to its few hardware
@@ -1002,17 +1065,18 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     hipStream_t s2 = side ? side : s;
     hipEventRecord(w->ev_in, s);
     hipStreamWaitEvent(s2, w->ev_in, 0);
-    hipLaunchKernelGGL(k_edt_bb, dim3(B), dim3(LGL_BB_T), 0, s2, w->bits, H, W, WW, w->qa, w->qb, w->best, w->bbflag);
+    hipLaunchKernelGGL(k_rowocc, dim3(std::max(4, std::min(64, 2048 / B)), B), dim3(256), 0, s2, w->bits, H, WW, w->occ);
+    hipLaunchKernelGGL(k_edt_bb, dim3(B), dim3(LGL_BB_T), 0, s2, w->bits, w->occ, H, W, WW, w->qa, w->qb, w->best, w->bbflag);
     hipEventRecord(w->ev_side, s2);
     hipLaunchKernelGGL(k_prefix, dim3(B), dim3(64), 0, s, w->pres, w->pre, w->nlab);
-    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc, w->comp, w->comp_n, comp_stride, segcap);
+    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc, w->comp, w->comp_n, comp_stride, segcap, ablate);
     // exact medians: ranks from the areas, 4 radix passes over the leaf-pixel list, successor for even counts
-    hipLaunchKernelGGL(k_seed, dim3(LGL_MAXL / 256, B), dim3(256), 0, s, w->acc, w->st);
+    hipLaunchKernelGGL(k_seed, dim3(LGL_MAXL / 256, B), dim3(256), 0, s, w->acc, w->st, w->maxpass);
     for (int pass = 3; pass >= 0; pass--) {
-        hipLaunchKernelGGL(k_hist, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, pass, w->hist);
-        hipLaunchKernelGGL(k_select, dim3(LGL_MAXL / 64, B), dim3(64), 0, s, w->st, w->hist, w->nlab, pass);
+        hipLaunchKernelGGL(k_hist<16>, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, w->maxpass, pass, w->hist,
+                           w->above, ablate);
+        hipLaunchKernelGGL(k_select, dim3(16, B), dim3(256), 0, s, w->st, w->hist, w->nlab, w->maxpass, pass, w->above, w->succ);
     }
-    hipLaunchKernelGGL(k_successor, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, w->succ);
     hipStreamWaitEvent(s, w->ev_side, 0);   // join: `best` is read back below
 
     // results in their final form: one pack kernel, one copy into pinned memory

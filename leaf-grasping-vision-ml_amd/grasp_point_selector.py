@@ -294,6 +294,10 @@ class GraspPointSelector:
             res = self.select_grasp_points_batch(leaf_mask, depth_tensor, image_processor=image_processor)[0]
             if res[0] is None:
                 logwarn("No valid candidate points found")
+            elif pcl_data is not None:
+                # get_3d_grasp_point's point-cloud branch reads self.width, which the class never defines (:164-178): the
+                # reference raises there and ends in its logged None triple
+                raise AttributeError("'GraspPointSelector' object has no attribute 'width'")
             return res
         except Exception as e:  # noqa: BLE001
             logerr(f"Error in grasp point selection: {str(e)}")

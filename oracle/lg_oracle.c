@@ -24,6 +24,10 @@
 #include <string.h>
 
 #define LG_DIST_SHIFT 16
+/* OpenCV's INIT_DIST0: INT_MAX >> 2 in the 2.4 / 3.x sources this restatement started from; revisions that lifted the
+   8192-pixel ceiling use INT_MAX with the same unsigned, saturating passes.  It only shows in the transform of an image
+   without any zero pixel (_calculate_isolation_score, :605-616).  opencv-python 4.10.0.84 is absent: the caller picks
+   (lg_chamfer_dt_ex), the default is the former.  PARITY UNPINNED either way. */
 #define LG_INIT_DIST0 (INT_MAX >> 2)
 
 static unsigned lg_flt_to_fix(float x) {
@@ -44,8 +48,8 @@ static unsigned lg_flt_to_fix(float x) {
  * src: H*W bytes, nonzero = inside (distance to nearest zero pixel).
  * fix_out (optional): the final fixed-point integers.
  */
-void lg_chamfer_dt(const uint8_t* src, int H, int W, int mask_size, float* dst,
-                   uint32_t* fix_out) {
+void lg_chamfer_dt_ex(const uint8_t* src, int H, int W, int mask_size, unsigned init_dist0, float* dst,
+                      uint32_t* fix_out) {
     const int BORDER = (mask_size == 3) ? 1 : 2;
     const unsigned HV = (mask_size == 3) ? lg_flt_to_fix(0.955f) : lg_flt_to_fix(1.0f);
     const unsigned DG = (mask_size == 3) ? lg_flt_to_fix(1.3693f) : lg_flt_to_fix(1.4f);
@@ -59,13 +63,13 @@ void lg_chamfer_dt(const uint8_t* src, int H, int W, int mask_size, float* dst,
     for (i = 0; i < BORDER; i++) {
         unsigned* top = temp + (size_t)i * step;
         unsigned* bot = temp + (size_t)(H + 2 * BORDER - i - 1) * step;
-        for (j = 0; j < step; j++) top[j] = bot[j] = LG_INIT_DIST0;
+        for (j = 0; j < step; j++) top[j] = bot[j] = init_dist0;
     }
     /* forward pass */
     for (i = 0; i < H; i++) {
         const uint8_t* s = src + (size_t)i * W;
         unsigned* tmp = temp + (size_t)(i + BORDER) * step + BORDER;
-        for (j = 0; j < BORDER; j++) tmp[-j - 1] = tmp[W + j] = LG_INIT_DIST0;
+        for (j = 0; j < BORDER; j++) tmp[-j - 1] = tmp[W + j] = init_dist0;
         for (j = 0; j < W; j++) {
             if (!s[j]) {
                 tmp[j] = 0;
@@ -141,6 +145,10 @@ void lg_chamfer_dt(const uint8_t* src, int H, int W, int mask_size, float* dst,
         }
     }
     free(temp);
+}
+
+void lg_chamfer_dt(const uint8_t* src, int H, int W, int mask_size, float* dst, uint32_t* fix_out) {
+    lg_chamfer_dt_ex(src, H, W, mask_size, (unsigned)LG_INIT_DIST0, dst, fix_out);
 }
 
 /*

@@ -54,6 +54,8 @@ def _lib():
         u8p = ctypes.POINTER(ctypes.c_uint8)
         L.lg_chamfer_dt.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
+        L.lg_chamfer_dt_ex.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint32)]
         L.lg_chamfer_dt.restype = None
         L.lg_ellipse_se.argtypes = [ctypes.c_int, u8p]
         L.lg_dilate.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int, u8p]
@@ -76,14 +78,17 @@ def _u8(a):
 
 
 # --------------------------------------------------------------------------- cv2 stand-ins
-def distance_transform(src_u8, mask_size=5, return_fix=False):
+INIT_DIST0 = (2 ** 31 - 1) >> 2   # OpenCV's border initialiser: INT_MAX >> 2, or INT_MAX in later revisions (lg_oracle.c)
+
+
+def distance_transform(src_u8, mask_size=5, return_fix=False, init_dist0=INIT_DIST0):
     """cv2.distanceTransform(src, cv2.DIST_L2, mask_size) -> float32 [H,W]  (lg_oracle.c)."""
     a, p = _u8(src_u8)
     H, W = a.shape
     out = np.empty((H, W), np.float32)
     fix = np.empty((H, W), np.uint32)
-    _lib().lg_chamfer_dt(p, H, W, int(mask_size), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                         fix.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    _lib().lg_chamfer_dt_ex(p, H, W, int(mask_size), int(init_dist0), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                            fix.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
     return (out, fix) if return_fix else out
 
 
@@ -249,7 +254,8 @@ class RefGraspPointSelector:
     """Restatement of scripts/utils/grasp_point_selector.py::GraspPointSelector (CV maps, candidates,
     CNN rescoring loop, 3-D back-projection, pre-grasp).  numpy in, numpy out."""
 
-    def __init__(self, cnn=None, gaussian_size=5):
+    def __init__(self, cnn=None, gaussian_size=5, init_dist0=INIT_DIST0):
+        self.init_dist0 = init_dist0   # OpenCV's INIT_DIST0 (library-revision dependent, see distance_transform)
         self.camera_cx = 707  # grasp_point_selector.py:29-31
         self.camera_cy = 494
         self.f_norm = None
@@ -294,8 +300,8 @@ class RefGraspPointSelector:
     # :526-567
     def calculate_sdf_score(self, m, return_parts=False):
         m = np.ascontiguousarray(m, np.uint8)
-        dist_inside = distance_transform(m, 5)
-        dist_outside = distance_transform(1 - m, 5)
+        dist_inside = distance_transform(m, 5, init_dist0=self.init_dist0)
+        dist_outside = distance_transform(1 - m, 5, init_dist0=self.init_dist0)
         sdf = dist_inside - dist_outside
         optimal_distance = 20
         interior = np.exp(-((dist_inside - optimal_distance) ** 2) / (2 * optimal_distance ** 2))
@@ -327,10 +333,10 @@ class RefGraspPointSelector:
         all_leaves = (m > 0).astype(np.uint8)
         other = all_leaves - current
         ic = dilate(other, kernel_close)
-        dc = distance_transform(1 - ic, 3)
+        dc = distance_transform(1 - ic, 3, init_dist0=self.init_dist0)
         sc = dc / (np.max(dc) + 1e-6)
         iw = dilate(other, kernel_wide)
-        dw = distance_transform(1 - iw, 3)
+        dw = distance_transform(1 - iw, 3, init_dist0=self.init_dist0)
         sw = dw / (np.max(dw) + 1e-6)
         iso = (0.7 * sc + 0.3 * sw).astype(np.float32)  # float32 array * python float stays float32
         yc = np.linspace(1.0, 0.2, height)[:, np.newaxis]
@@ -357,7 +363,7 @@ class RefGraspPointSelector:
             "flatness_map": flatness_map(np.asarray(depth_f32, np.float32) * m.astype(np.float32),
                                          self.gaussian_size),
             "isolation_map": self._calculate_isolation_score(m),
-            "distance_map": distance_transform(m, 5),  # :266 (recomputed by the reference)
+            "distance_map": distance_transform(m, 5, init_dist0=self.init_dist0),  # :266 (recomputed by the reference)
             "accessibility_map": self._calculate_accessibility_score(m),
             "stem_penalty": self._calculate_stem_penalty(m).astype(np.float32),
         }
@@ -380,8 +386,9 @@ class RefGraspPointSelector:
         flat = vs.ravel() + 0.0  # -0.0 -> +0.0
         if tie_rule == "numpy":
             order = np.argsort(flat)[::-1]
-        else:
-            order = np.lexsort((-np.arange(flat.size), -flat))
+        else:   # NaN first (np.argsort sorts NaN last, the reference reverses the order), then score desc, then flat index desc
+            nan = np.isnan(flat)
+            order = np.lexsort((-np.arange(flat.size), -np.where(nan, 0.0, flat), ~nan))
         order = np.ascontiguousarray(order, np.int64)
         out = np.zeros((top_k, 2), np.int32)
         n = _lib().lg_greedy_nms(order.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), order.size, H, W,
@@ -439,19 +446,24 @@ class RefGraspPointSelector:
 
     # :754-819
     def calculate_pre_grasp_point(self, g3, m):
-        g = np.array(g3, dtype=np.float64)
-        direction = g / np.linalg.norm(g)
-        dil = dilate(m, ellipse_se(31))
-        min_d, max_d, step = 0.05, 0.10, 0.01
-        for dist in np.arange(min_d, max_d, step):
-            t = (g3[0] - direction[0] * dist, g3[1] - direction[1] * dist, g3[2])
-            u, v = self._project_point_to_2d(t)
-            if not (0 <= u < m.shape[1] and 0 <= v < m.shape[0]):
-                continue
-            if dil[v, u] == 0:
-                if np.linalg.norm(np.array(t) - g) >= min_d:
-                    return t
-        return (g3[0] - direction[0] * max_d, g3[1] - direction[1] * max_d, g3[2])
+        try:
+            g = np.array(g3, dtype=np.float64)
+            with np.errstate(all="ignore"):
+                direction = g / np.linalg.norm(g)
+            dil = dilate(m, ellipse_se(31))
+            min_d, max_d, step = 0.05, 0.10, 0.01
+            for dist in np.arange(min_d, max_d, step):
+                t = (g3[0] - direction[0] * dist, g3[1] - direction[1] * dist, g3[2])
+                with np.errstate(all="ignore"):
+                    u, v = self._project_point_to_2d(t)   # int(nan) / int(inf) raise, as in the reference
+                if not (0 <= u < m.shape[1] and 0 <= v < m.shape[0]):
+                    continue
+                if dil[v, u] == 0:
+                    if np.linalg.norm(np.array(t) - g) >= min_d:
+                        return t
+            return (g3[0] - direction[0] * max_d, g3[1] - direction[1] * max_d, g3[2])
+        except Exception:   # :817-819: logged, None (a grasp point whose depth is NaN, infinite or 0 has no pre-grasp point)
+            return None
 
     # :184-253
     def select_grasp_point(self, m, depth_f32, tie_rule="total", mask_is_bool=True, return_debug=False):

@@ -222,6 +222,34 @@ def test_row_search_on_hard_masks(dt_sels, form):
         assert sel.dt_maxima(i)[0] == exp[i].max(), f"batched mask {i}"
 
 
+def test_chamfer_init_dist0_is_a_parameter(L):
+    """OpenCV's INIT_DIST0 shows in the transform of an image without a zero pixel: the isolation map (always: other_leaves == 0,
+    grasp_point_selector.py:605-616) and dist_inside of an all-ones mask.  Which constant the pinned opencv-python 4.10.0.84 uses
+    cannot be checked here: both INT_MAX >> 2 (default) and INT_MAX go through lg_params.chamfer_init_dist0
+    and must give the oracle's planes for the same value; the two differ from each other by a few per cent."""
+    s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    H, W = 270, 360
+    labels, depth, P = O.synthetic_scene(H, W, 1)
+    s.set_camera_params(P)
+    iso = {}
+    for init0 in (O.INIT_DIST0, 2 ** 31 - 1):
+        s.params.chamfer_init_dist0 = init0
+        for mask in ((labels == 1).astype(np.uint8), np.ones((H, W), np.uint8)):
+            maps, valid, _ = s.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(depth).cuda())
+            ref = O.RefGraspPointSelector(init_dist0=init0)
+            ref.set_camera_params(P)
+            sc = ref._calculate_all_scores(mask, depth)
+            np.testing.assert_array_equal(maps["distance_map"].cpu().numpy(), sc["distance_map"])
+            for k, v in sc.items():
+                np.testing.assert_allclose(maps[k].cpu().numpy(), v, rtol=RTOL, atol=ATOL, err_msg=f"{k} init {init0}")
+            np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), ref._get_valid_regions(mask, sc))
+        iso[init0] = maps["isolation_map"].cpu().numpy()
+    a, b = iso[O.INIT_DIST0], iso[2 ** 31 - 1]
+    assert 0.005 < np.max(np.abs(a - b)) < 0.08          # the same ramp, a few per cent apart
+    s.params.chamfer_init_dist0 = 12345                   # below INT_MAX >> 2: refused, the reference-style None triple
+    assert s.select_grasp_point(torch.from_numpy(labels == 1).cuda(), torch.from_numpy(depth).cuda(), None) == (None, None, None)
+
+
 def test_batch_equals_single(sel):
     H, W = 135, 180
     frames = [O.synthetic_scene(H, W, s) for s in range(5)]
@@ -749,18 +777,99 @@ def test_batched_select_equals_single_calls_1080p(L, sel, monkeypatch):
     sel.clear_cnn()
 
 
-def test_non_finite_depth_does_not_hang_or_raise(sel):
+def _same_triple(got, exp):
+    """(xy, XYZ, preXYZ) triples with NaN-aware comparison of the floats."""
+    assert (got[0] is None) == (exp[0] is None) and (got[2] is None) == (exp[2] is None), (got, exp)
+    if exp[0] is None:
+        return
+    assert tuple(got[0]) == tuple(exp[0]), (got, exp)
+    np.testing.assert_allclose(np.array(got[1], np.float64), np.array(exp[1], np.float64), rtol=1e-5, equal_nan=True)
+    if exp[2] is not None:
+        np.testing.assert_allclose(np.array(got[2], np.float64), np.array(exp[2], np.float64), rtol=1e-5, equal_nan=True)
+
+
+def test_nan_depth_on_the_leaf_follows_the_reference(sel):
+    """grasp_point_selector.py:262 multiplies depth by the mask and :451 multiplies the fused score by the validity mask: a NaN
+    depth pixel ON the leaf makes flatness / traditional NaN over the 7 x 7 reach of the Gaussian and the Sobel, NaN * 0 stays
+    NaN for pixels that are not valid, and np.argsort(...)[::-1] (:454) lists NaN pixels FIRST.  The planes, the validity
+    mask, the candidate list (NaN first, then score, ties by flat index: DESIGN 2 quirk 3) and the triple must equal the
+    oracle's; a grasp point whose own depth is NaN has NaN coordinates and no pre-grasp point (:817-819)."""
+    H, W = 400, 520
+    labels, depth, P = O.synthetic_scene(H, W, 5)
+    ids, cnt = np.unique(labels[labels > 0], return_counts=True)
+    mask = (labels == ids[np.argmax(cnt)]).astype(np.uint8)
+    ys, xs = np.nonzero(mask)
+    cy, cx = int(ys.mean()), int(xs.mean())
+    corner = np.zeros((H, W), np.uint8)
+    corner[H - 150:, W - 200:] = 1      # a leaf in the frame's last rows and columns: the NaN reach ends at pixel (H-1, W-1) itself
+    for case, (mask, pts) in enumerate(((mask, [(cy, cx)]),
+                                        (mask, [(cy - 30, cx - 20), (cy + 25, cx + 40), (ys.min(), xs[ys.argmin()])]),
+                                        (corner, [(H - 1, W - 1), (H - 60, W - 70)]))):
+        d = depth.copy()
+        for (y, x) in pts:
+            assert mask[y, x]
+            d[y, x] = np.nan
+        sel.set_camera_params(P)
+        maps, valid, _ = sel.score_maps(torch.from_numpy(mask).cuda(), torch.from_numpy(d).cuda())
+        ref = _oracle(P)
+        with np.errstate(all="ignore"):
+            sc = ref._calculate_all_scores(mask, d)
+            exp_valid = ref._get_valid_regions(mask, sc)
+        assert np.isnan(sc["traditional_score"]).sum() >= 49
+        for k, v in sc.items():
+            np.testing.assert_allclose(maps[k].cpu().numpy(), v, rtol=RTOL, atol=ATOL, equal_nan=True, err_msg=f"case {case} {k}")
+        np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), exp_valid)
+        with np.errstate(all="ignore"):
+            exp_c = ref._get_candidate_points(sc["traditional_score"], exp_valid, 20, 10)
+            exp = ref.select_grasp_point(mask, d)
+        got_c = sel._get_candidate_points(maps["traditional_score"], valid, 20, 10)
+        assert [tuple(c) for c in got_c] == [tuple(c) for c in exp_c], f"case {case}"
+        assert np.isnan(sc["traditional_score"][exp_c[0][1], exp_c[0][0]])     # a NaN pixel leads the list
+        got = sel.select_grasp_point(torch.from_numpy(mask.astype(bool)).cuda(), torch.from_numpy(d).cuda(), None)
+        _same_triple(got, exp)
+        if case == 2:
+            assert got[0] is not None and np.isnan(got[1][2]) and got[2] is None   # the chosen pixel's own depth is NaN
+
+
+def test_non_finite_depth_off_the_leaf_is_ignored(sel):
+    """DESIGN 2 quirk 9 (a deliberate deviation): the reference's depth * mask turns a NaN / infinite depth pixel OFF the leaf into
+    NaN (NaN * 0), which then spreads through flatness and the fused score; here depth * mask is a selection -- tiles without a
+    leaf pixel in stencil reach never read depth at all -- so such a pixel counts as the 0 every finite depth gives.  Asserted: the
+    outputs equal those of the same frame with these pixels set to 1.0; the distance transform never touches depth."""
     H, W = 270, 360
     labels, depth, P = O.synthetic_scene(H, W, 1)
     sel.set_camera_params(P)
+    mask = labels == 1
+    ys, xs = np.nonzero(mask)
     d = depth.copy()
-    d[100:140, 150:200] = np.nan
+    off = ~mask
+    d[100:140, 150:200][off[100:140, 150:200]] = np.nan
     d[10, 10] = np.inf
-    res = sel.select_grasp_point(torch.from_numpy(labels == 1).cuda(), torch.from_numpy(d).cuda(), None)
-    assert isinstance(res, tuple) and len(res) == 3
-    maps, valid, _ = sel.score_maps(torch.from_numpy((labels == 1).astype(np.uint8)).cuda(), torch.from_numpy(d).cuda())
-    dm = maps["distance_map"].cpu().numpy()
-    np.testing.assert_array_equal(dm, O.distance_transform((labels == 1).astype(np.uint8), 5))  # depth never touches the DT
+    d[ys.min() - 1, xs[ys.argmin()]] = -np.inf          # right next to the leaf: inside the stencil reach
+    clean = np.where(off & ~np.isfinite(d), np.float32(1.0), d)
+    assert np.isfinite(clean).all()
+    m8 = torch.from_numpy(mask.astype(np.uint8)).cuda()
+    maps, valid, _ = sel.score_maps(m8, torch.from_numpy(d).cuda())
+    maps2, valid2, _ = sel.score_maps(m8, torch.from_numpy(clean).cuda())
+    for k in maps:
+        np.testing.assert_array_equal(maps[k].cpu().numpy(), maps2[k].cpu().numpy(), err_msg=k)
+    np.testing.assert_array_equal(valid.cpu().numpy(), valid2.cpu().numpy())
+    np.testing.assert_array_equal(maps["distance_map"].cpu().numpy(), O.distance_transform(mask.astype(np.uint8), 5))
+    res = sel.select_grasp_point(torch.from_numpy(mask).cuda(), torch.from_numpy(d).cuda(), None)
+    res2 = sel.select_grasp_point(torch.from_numpy(mask).cuda(), torch.from_numpy(clean).cuda(), None)
+    _same_triple(res, res2)
+
+
+def test_pcl_data_ends_in_the_logged_none_triple(sel):
+    """get_3d_grasp_point's point-cloud branch reads the undefined self.width (grasp_point_selector.py:164-178): with pcl_data the
+    reference raises inside select_grasp_point, logs and returns (None, None, None) -- so does the mirror."""
+    H, W = 270, 360
+    labels, depth, P = O.synthetic_scene(H, W, 1)
+    sel.set_camera_params(P)
+    m, d = torch.from_numpy(labels == 1).cuda(), torch.from_numpy(depth).cuda()
+    assert sel.select_grasp_point(m, d, None)[0] is not None
+    assert sel.select_grasp_point(m, d, None, pcl_data=np.zeros((H * W, 3), np.float32)) == (None, None, None)
+    assert sel.select_grasp_point(m, d, None, pcl_data=[]) == (None, None, None)
 
 
 def test_uint8_mask_with_255_values(sel):

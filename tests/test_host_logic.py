@@ -39,7 +39,7 @@ def test_default_params_are_the_reference_constants():
 
 def test_struct_sizes_match_header_layout():
     import ctypes as C
-    assert C.sizeof(_lib.LgParams) == 3 * 8 + 24 * 4  # 3 doubles, 17 floats, 7 int32
+    assert C.sizeof(_lib.LgParams) == 3 * 8 + 26 * 4  # 3 doubles, 17 floats, 9 int32
     assert C.sizeof(_lib.LgGraspResult) == 14 * 4
     assert C.sizeof(_lib.LgLeafStat) == 4 * 4 + 4 * 8 + 2 * 4
 
