@@ -104,6 +104,48 @@ def final_kernel_bytes(masks_np, wins, H, W, tile_w=64, tile_h=16):
     return total
 
 
+def kernel_fracs(kern_ms, masks_np, wins, B, H, W, K=20):
+    """Compulsory HBM bytes (read once + written once) of ONE launch of every score-path kernel beside the
+    plane kernel, for these masks, its average duration and the fraction of the 8 TB/s peak that makes.  Latency-bound kernels
+    (one workgroup per frame, bit rows only) show as the small fractions they are.  `wins[i]` = (x0, x1, y0, y1): frame i's
+    distance-transform window as the library reports it (lg_debug_dt_max).  kern_ms: name -> average ms."""
+    nd = len(masks_np)
+    WW = (W + 63) // 64
+    bits = H * WW * 8                               # one frame's bit rows
+    per = {k: 0.0 for k in ("prep", "bbox", "stem", "orient", "dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "dt_border",
+                            "topk", "gather")}
+    for m, (wx0, wx1, wy0, wy1) in zip(masks_np, wins):
+        ys, xs = np.nonzero(m)
+        win_px = (wx1 - wx0) * (wy1 - wy0)
+        if ys.size:
+            bb_rows, bb_words = ys.max() - ys.min() + 3, xs.max() // 64 - xs.min() // 64 + 1
+        else:
+            bb_rows = bb_words = 0
+        per["prep"] += H * W * 1 + bits             # mask bytes in, bit rows out
+        per["bbox"] += bits
+        per["stem"] += 2 * bits // 3 + bits // 3    # the bottom third's bit rows in (with the 15-row reach), stem rows out
+        per["orient"] += bb_rows * bb_words * 8
+        per["dt_border"] += bb_rows * bb_words * 8
+        # row search: run distances (2 B per pixel of the bounding box's words) written once, read once; distance_map written
+        per["dt_hrun"] += bb_rows * bb_words * (8 + 128)
+        if "dt_band" in kern_ms:                    # anchors (every 8th row: distance + minimising row) / the rows between
+            per["dt_search"] += bb_rows * bb_words * 128 // 8 + win_px * (4 + 2) // 8
+            per["dt_band"] += bb_rows * bb_words * 128 + win_px * 2 // 8 + win_px * 4 * 7 // 8
+        else:
+            per["dt_search"] += bb_rows * bb_words * 128 + win_px * 4
+        per["dt_fwd"] += win_px * (1 + 4)           # sweeps (frames that take them): mask in, forward values out; those in, distance out
+        per["dt_bwd"] += win_px * (4 + 4)
+        tiles = ((W + 63) // 64) * ((H + 15) // 16)
+        per["topk"] += tiles * 8 + K * 8 * 1024 * 5  # tile keys + the <= 8 tiles a pick's suppression window touches (score + valid)
+        per["gather"] += K * (9 * 32 * 32 * 4 + 12 * 34 * 36 * 4)
+    out = {}
+    for k, tot in per.items():
+        if k in kern_ms and kern_ms[k] > 0:
+            b = tot * (B / nd)
+            out[k] = {"bytes": round(b), "avg_ms": round(kern_ms[k], 4), "frac": round(b / (kern_ms[k] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+    return out
+
+
 def cpu_baseline(H, W, P, params, n_frames, threads):
     """Restated reference-equivalent CPU path (oracle, NumPy/torch-CPU + C chamfer): same work as
     scripts/utils/grasp_point_selector.py::select_grasp_point.  NOT the reference's own timing
@@ -211,6 +253,16 @@ def secondary_configs(args, dev, L, lib, SI, params, P, extra_frames, masks_np, 
             t0 = time.perf_counter()
             r1 = sel.select_grasp_point(m1, d1, ip)
             ts.append(time.perf_counter() - t0)
+        lib.lg_profile_enable(sel._h, 1)
+        sel.select_grasp_point(m1, d1, ip)
+        k1 = {}
+        for name in ("prep", "bbox", "orient", "stem", "dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "dt_border", "final", "topk",
+                     "gather", "cnn", "finish"):
+            n_, ms_ = C.c_int(0), C.c_double(0.0)
+            lib.lg_profile_read(sel._h, name.encode(), C.byref(n_), C.byref(ms_))
+            if n_.value:
+                k1[name] = round(ms_.value / n_.value, 4)
+        lib.lg_profile_enable(sel._h, 0)
         hz = L.LeafGraspHarness(H, W, dev, load_model=False)
         hz.camera_info_callback(np.asarray(P).reshape(-1))
         hz.grasp_selector.set_cnn_state_dict(params)
@@ -226,6 +278,7 @@ def secondary_configs(args, dev, L, lib, SI, params, P, extra_frames, masks_np, 
         out["1080p_b1_latency_ms"] = {"select_grasp_point": round(1e3 * float(np.median(ts)), 4),
                                       "select_grasp_point_min": round(1e3 * float(np.min(ts)), 4),
                                       "node_sequence": round(1e3 * float(np.median(tn)), 4), "found": r1[0] is not None and csv is not None,
+                                      "kernels_ms": k1,
                                       "what": "median wall time of one call on one resident frame (label / mask + depth tensors on the "
                                               "device): GraspPointSelector.select_grasp_point incl. CNN, and the node's whole "
                                               "select_optimal_leaf sequence (leaf selection + grasp selection)"}
@@ -452,6 +505,12 @@ def main():
                                "bytes_per_launch": round(launch_bytes),
                                "bytes_per_px": round(launch_bytes / px, 3), "dense_bytes_per_px": FINAL_BYTES_PER_PX,
                                "distinct_scenes": n_distinct}
+        try:   # every other kernel of the path: compulsory bytes, average duration, fraction of the HBM peak
+            n_distinct = min(B, N_DISTINCT)
+            wins_k = [sels[0].dt_maxima(i)[2] for i in range(n_distinct)]
+            out["kernel_fracs"] = kernel_fracs({k: v["avg_ms"] for k, v in kern.items()}, masks_np[:n_distinct], wins_k, B, H, W)
+        except Exception as e:  # noqa: BLE001
+            out["kernel_fracs"] = {"error": str(e)}
         if "cnn" in kern and not args.no_cnn:
             # MFMA flops actually executed per 9x32x32 patch (2 x MACs): Winograd F(4x4,3x3) = 36 positions x Cout x Cin x
             # tiles (4x fewer than direct), layer 0 on 12 padded input planes; F(2x2,3x3) = 16 positions (2.25x fewer) with
@@ -626,36 +685,50 @@ def main():
                     d_depth.copy_(h_depth, non_blocking=True)
                 torch.cuda.synchronize(dev)
                 dt_c = time.perf_counter() - t_c
-                # the same with the NEXT batch's copy in flight on a second stream (two device buffers) while this one is scored
-                cs = torch.cuda.Stream(device=dev)
+                # the same with the NEXT batch's copy in flight on a second stream (two device buffers) while this one is scored.
+                # Which stream: ROCm deals a process's streams onto a few hardware queues in creation order, and a copy stream that
+                # lands on the queue of the stream the scoring runs on (or of one of the selector's own streams) runs behind the
+                # scoring instead of beside it -- whether it does depends on how many streams the process created before
+                # (tools/h2d_probe.py: 5331 vs 4458 frames/s for the same code after three more selectors had come and gone; that,
+                # not the library, is what BENCH_r03's h2d figure lost against BENCH_r02's).  So: a few candidate streams (one of
+                # them high priority: a queue of its own), two overlapped steps with each, the fastest one carries the copies --
+                # what a deployment would do once at start-up.
                 bufs = [(d_mask, d_depth), (torch.empty_like(d_mask), torch.empty_like(d_depth))]
                 evs = [torch.cuda.Event(), torch.cuda.Event()]
 
-                def issue_copy(k):
-                    with torch.cuda.stream(cs):
-                        bufs[k][0].copy_(h_mask, non_blocking=True)
-                        bufs[k][1].copy_(h_depth, non_blocking=True)
-                        evs[k].record(cs)
+                def overlapped(cs_, n_):
+                    def issue_copy(k):
+                        with torch.cuda.stream(cs_):
+                            bufs[k][0].copy_(h_mask, non_blocking=True)
+                            bufs[k][1].copy_(h_depth, non_blocking=True)
+                            evs[k].record(cs_)
+                    torch.cuda.synchronize(dev)
+                    t0_ = time.perf_counter()
+                    issue_copy(0)
+                    r_ = None
+                    for i in range(n_):
+                        evs[i % 2].synchronize()
+                        if i + 1 < n_:
+                            issue_copy((i + 1) % 2)
+                        r_ = sels[0].select_grasp_points_batch(bufs[i % 2][0].view(torch.bool), bufs[i % 2][1])
+                    torch.cuda.synchronize(dev)
+                    return time.perf_counter() - t0_, r_
+                cands = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1),
+                         torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+                probe = [round(1e3 * overlapped(c_, 2)[0] / 2, 3) for c_ in cands]
+                cs = cands[int(np.argmin(probe))]
                 n_o = 2 * args.h2d_steps
-                torch.cuda.synchronize(dev)
-                t_o = time.perf_counter()
-                issue_copy(0)
-                for i in range(n_o):
-                    evs[i % 2].synchronize()
-                    if i + 1 < n_o:
-                        issue_copy((i + 1) % 2)
-                    r_o = sels[0].select_grasp_points_batch(bufs[i % 2][0].view(torch.bool), bufs[i % 2][1])
-                torch.cuda.synchronize(dev)
-                dt_o = time.perf_counter() - t_o
+                dt_o, r_o = overlapped(cs, n_o)
                 out["h2d_inclusive"] = {"value": round(nh * n_o / dt_o, 1), "unit": "frames/s",
                                         "frames_per_step": nh, "steps": n_o,
                                         "serial_value": round(nh * args.h2d_steps / dt_h, 1),
                                         "copy_only_GBps": round(nh * H * W * 5 * args.h2d_steps / dt_c / 1e9, 2),
+                                        "copy_stream_probe_ms_per_step": probe,
                                         "what": "pinned host depth f32 + mask u8 -> device, then the scoring pass incl. CNN; value: "
                                                 "the next batch's copy runs on a second stream beside the scoring of this one (two "
                                                 "device buffers); serial_value: copy and scoring on one stream, one after the other"}
                 assert all(r[0] is not None for r in r_h) and all(r[0] is not None for r in r_o)
-                h_mask = h_depth = d_mask = d_depth = bufs = None
+                h_mask = h_depth = d_mask = d_depth = bufs = cands = cs = None
             except Exception as e:  # noqa: BLE001
                 out["h2d_inclusive"] = {"error": str(e)}
         if world == 1 and args.node_steps > 0 and not args.no_cnn:
@@ -676,6 +749,41 @@ def main():
                     csvs = hz.process_batch_device(lab, dep)
                 torch.cuda.synchronize(dev)
                 dt_n = time.perf_counter() - t_n
+                # the leaf stage on its own (lg_leaf_select_batch): wall time, per-kernel event times, fraction of its 6 B/px bound
+                try:
+                    ols = hz.leaf_scorer
+                    ols.select_optimal_leaves_batch(lab, dep)
+                    torch.cuda.synchronize(dev)
+                    t_l = time.perf_counter()
+                    for _ in range(args.node_steps):
+                        ols.select_optimal_leaves_batch(lab, dep)
+                    torch.cuda.synchronize(dev)
+                    dt_l = (time.perf_counter() - t_l) / args.node_steps
+                    lib.lg_profile_enable(ols._h, 1)
+                    ols.select_optimal_leaves_batch(lab, dep)
+                    lk = {}
+                    for name in ("leaf_presence", "leaf_accumulate", "leaf_hist", "leaf_select", "leaf_edt", "leaf_pack"):
+                        n_, ms_ = C.c_int(0), C.c_double(0.0)
+                        lib.lg_profile_read(ols._h, name.encode(), C.byref(n_), C.byref(ms_))
+                        if n_.value:
+                            lk[name] = round(ms_.value, 4)      # total per call (leaf_hist / leaf_select: all passes)
+                    lib.lg_profile_enable(ols._h, 0)
+                    leaf_px = float(np.mean([(labels_np[i % nsc] > 0).sum() for i in range(nb)]))
+                    lbytes = {"leaf_presence": nb * (H * W * 2 + H * ((W + 63) // 64) * 8),
+                              "leaf_accumulate": nb * (H * W * 2 + leaf_px * (4 + 8)),
+                              "leaf_hist": nb * leaf_px * 8 * 3,
+                              "leaf_edt": nb * H * ((W + 63) // 64) * 8 * 2}
+                    out["leaf_stage"] = {"ms_per_call": round(1e3 * dt_l, 4), "frames_per_call": nb,
+                                         "frames_per_s": round(nb / dt_l, 1),
+                                         "frac_of_6B_per_px_bound": round(nb * H * W * 6 / dt_l / (HBM_PEAK_GBS * 1e9), 4),
+                                         "kernels_ms": lk,
+                                         "kernel_fracs": {k: round(v / (lk[k] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) for k, v in lbytes.items() if lk.get(k)},
+                                         "leaf_pixels_per_frame": round(leaf_px),
+                                         "what": "lg_leaf_select_batch on the int16 label + depth frames (leaf_scorer.py:25-203): compulsory "
+                                                 "traffic 6 B/px; kernels_ms = event time per call on the kernel's own stream (leaf_edt runs "
+                                                 "beside the statistics chain); kernel_fracs = that kernel's compulsory bytes / its time / 8 TB/s"}
+                except Exception as e:  # noqa: BLE001
+                    out["leaf_stage"] = {"error": str(e)}
                 out["node_sequence"] = {"value": round(nb * args.node_steps / dt_n, 1), "unit": "frames/s",
                                         "frames_per_step": nb, "steps": args.node_steps,
                                         "results": sum(c is not None for c in csvs),

@@ -148,6 +148,9 @@ typedef struct lg_leaf_stat {
 int lg_create(int device, lg_handle* out);
 int lg_destroy(lg_handle h);
 const char* lg_last_error(lg_handle h);
+/* "" normally; why the device-side contour analysis (estimate_leaf_orientation, :718-752) could not be set up for this handle's
+   workspace -- scoring then goes on with the host analysis of every frame (same results). */
+const char* lg_orientation_note(lg_handle h);
 const char* lg_version(void);
 void lg_default_params(lg_params* p);
 
@@ -165,6 +168,8 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
    the gaussian_size x gaussian_size kernel of _create_gaussian_kernel (:25-32, sigma = size / 6) applied as its two 1-D
    factors.  depth [B][H][W] f32 DEVICE -> out [B][Ho][Wo] f32 DEVICE, Ho = H + 2 (size / 2) - size + 1 (= H for odd sizes,
    H + 1 for even ones, as F.conv2d returns); 1 <= gaussian_size <= 15, gaussian_size / 2 < min(H, W).
+   Stateless: only the handle's device is used and nothing of the handle is written, so threads may share a handle here (it takes
+   no part in the one-call-in-flight rule); the reason of a failure is per thread: lg_last_error(NULL).
    lg_gaussian_taps: that 1-D factor (HOST, gaussian_size floats) -- what the plane kernel and lg_smooth_depth multiply with. */
 int lg_smooth_depth(lg_handle h, const float* depth, int B, int H, int W, int gaussian_size, float* out, void* stream);
 int lg_gaussian_taps(int gaussian_size, float* taps);

@@ -60,6 +60,7 @@ SYMBOLS = {
     "lg_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "lg_destroy": (C.c_int, [_VP]),
     "lg_last_error": (C.c_char_p, [_VP]),
+    "lg_orientation_note": (C.c_char_p, [_VP]),
     "lg_version": (C.c_char_p, []),
     "lg_default_params": (None, [C.POINTER(LgParams)]),
     "lg_score_maps": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(LgParams),

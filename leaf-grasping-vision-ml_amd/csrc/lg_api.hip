@@ -62,6 +62,7 @@ struct lg_ctx {
     lg_grasp_result* res_host = nullptr;      // pinned copy
     LgCnn cnn;
     LgLeafWs* leaf = nullptr;
+    LgLeafProf* leaf_prof = nullptr;   // per-kernel times of the leaf stage (lg_profile_enable)
     LgOrientWs* orient = nullptr;   // device-side orientation scratch (lg_orient.hip)
     hipEvent_t ev_orient = nullptr, ev_side = nullptr, ev_search = nullptr;
     int opt_dt_algo = 0;            // LG_DT_SEARCH_ALGO=1: one-level row search at every batch size; 2: anchors + bands (3 / 4: with four / one
@@ -223,7 +224,12 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
         // no device-side scratch (allocation, or the LDS request on a part with less of it): the host contour analysis of
         // every frame is a complete path of its own -- scoring goes on, the reason stays readable in orient_note
         std::string err;
-        if (lg_orient_ensure(h->orient, nB, H, &err)) { h->orient_note = err; lg_orient_free(h->orient); }
+        // (LG_ORIENT_FAIL, read here once per workspace: makes the set-up fail -- the test of this hand-over)
+        if (getenv("LG_ORIENT_FAIL") || lg_orient_ensure(h->orient, nB, H, &err)) {
+            h->orient_note = err.empty() ? "orientation scratch: LG_ORIENT_FAIL is set" : err;
+            lg_orient_free(h->orient);
+            (void)hipGetLastError();   // the failed allocation's error is sticky until read: it must not fail the call that goes on without it
+        }
     } else {
         lg_orient_free(h->orient);   // (a scratch sized for another image height must not outlive it: host analysis from here on)
     }
@@ -363,6 +369,7 @@ int lg_create(int device, lg_handle* out) {
         }
     }
     h->pool = new (std::nothrow) LgPool(h->host_threads - 1);  // the calling thread is the last worker
+    h->leaf_prof = lg_leaf_prof_new();
     *out = h;
     return LG_OK;
 }
@@ -377,6 +384,7 @@ int lg_destroy(lg_handle h) {
     free_ws(h);
     lg_cnn_free(&h->cnn);
     lg_leaf_free(h->leaf);
+    lg_leaf_prof_free(h->leaf_prof);
     lg_orient_free(h->orient);
     if (h->ev_orient) hipEventDestroy(h->ev_orient);
     if (h->ev_side) hipEventDestroy(h->ev_side);
@@ -398,11 +406,14 @@ int lg_destroy(lg_handle h) {
 
 const char* lg_last_error(lg_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }   // NULL: why lg_create failed
 
+const char* lg_orientation_note(lg_handle h) { return h ? h->orient_note.c_str() : ""; }
+
 int lg_profile_enable(lg_handle h, int on) {
     if (!h) return LG_ERR_INVALID;
     LG_ENTER(h);
     for (auto& p : h->prof) { p.used = 0; p.launches = 0; p.total_ms = 0.0; }
     h->prof_on = on < 0 ? 0 : on;
+    lg_leaf_prof_enable(h->leaf_prof, on == 1);
     return LG_OK;
 }
 
@@ -414,6 +425,7 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
     prof_flush(h);
     if (launches) *launches = 0;
     if (total_ms) *total_ms = 0.0;
+    if (lg_leaf_prof_read(h->leaf_prof, name, launches, total_ms)) return LG_OK;
     for (auto& p : h->prof)
         if (p.name == name) {
             if (launches) *launches = p.launches;
@@ -539,8 +551,9 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
             ProfScope ps(h, "dt_hrun", ss);
             lg_launch_hrun(h->bits + off * words, h->tmp + 2 * off * px, h->win + off, n, pl.H, pl.W, pl.WW, ss);
         }
-        // one-level search up to 64 frames (one launch, the device is not full), anchors + bands above (fewer evaluations)
-        const int algo = h->opt_dt_algo ? h->opt_dt_algo : (n <= 64 ? 1 : 2);
+        // one-level search up to 64 frames of 1080p (one launch, the device is not full), anchors + bands above (fewer evaluations:
+        // 64 frames of 4K 1.08 vs 1.54 ms, 32 of 1080p 0.18 vs 0.14 ms)
+        const int algo = h->opt_dt_algo ? h->opt_dt_algo : ((long long)n * pl.H * pl.W <= 64ll * 1080 * 1920 ? 1 : 2);
         for (int phase = 0; phase < (algo == 1 ? 1 : 2); phase++) {
             ProfScope ps(h, phase ? "dt_band" : "dt_search", ss);
             lg_launch_dtsearch(phase, algo, h->bits + off * words, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
@@ -665,6 +678,8 @@ int make_plan(lg_ctx* h, Plan& pl, const float* depth, const uint8_t* mask, int 
     // an (H+1) x (W+1) plane there and the fusion raises -> None triple; odd sizes above 7 exceed this kernel's halo
     if (pl.P.gaussian_size < 1 || pl.P.gaussian_size > 7 || (pl.P.gaussian_size & 1) == 0)
         return fail(h, LG_ERR_UNSUPPORTED, "gaussian_size must be 1, 3, 5 or 7 (an even size fails in the reference too: shape mismatch in the fusion)");
+    if (pl.P.gaussian_size / 2 >= std::min(H, W))   // torch's reflect padding refuses it: the reference ends in its None triple
+        return fail(h, LG_ERR_INVALID, "gaussian_size / 2 must be smaller than H and W (reflect padding)");
     if (pl.P.chamfer_init_dist0 < (int32_t)LG_INIT0)   // (a zeroed struct, or a value a real distance could reach)
         return fail(h, LG_ERR_INVALID, "chamfer_init_dist0 must be in [INT_MAX >> 2, INT_MAX] (lg_default_params: INT_MAX >> 2)");
     pl.B = B; pl.H = H; pl.W = W; pl.WW = (W + 63) / 64;
@@ -715,17 +730,22 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
 }
 
 int lg_smooth_depth(lg_handle h, const float* depth, int B, int H, int W, int gaussian_size, float* out, void* stream_) {
+    // Stateless: only the handle's device is read, nothing of the handle is written -- the Python ImageProcessor objects of a
+    // process share one handle per device across threads, so this entry point takes no part in the one-call-in-flight rule and
+    // leaves the handle's error string alone (the reason of a failure: lg_last_error(NULL), per thread).
     if (!h) return LG_ERR_INVALID;
-    if (!depth || !out || B < 1 || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_smooth_depth: bad argument");
-    if (gaussian_size < 1 || gaussian_size > LG_MAX_GAUSS) return fail(h, LG_ERR_UNSUPPORTED, "lg_smooth_depth: gaussian_size must be in [1,15]");
+    auto bad = [](int code, const char* what) { g_create_err = what; return code; };
+    if (!depth || !out || B < 1 || H < 1 || W < 1) return bad(LG_ERR_INVALID, "lg_smooth_depth: bad argument");
+    if (gaussian_size < 1 || gaussian_size > LG_MAX_GAUSS) return bad(LG_ERR_UNSUPPORTED, "lg_smooth_depth: gaussian_size must be in [1,15]");
     if (gaussian_size / 2 >= std::min(H, W))   // torch: "Padding size should be less than the corresponding input dimension"
-        return fail(h, LG_ERR_INVALID, "lg_smooth_depth: reflect padding (gaussian_size / 2) must be smaller than H and W");
-    LG_HIP(h, hipSetDevice(h->device));
+        return bad(LG_ERR_INVALID, "lg_smooth_depth: reflect padding (gaussian_size / 2) must be smaller than H and W");
+    if (hipSetDevice(h->device) != hipSuccess) return bad(LG_ERR_HIP, "lg_smooth_depth: hipSetDevice failed");
     LgGaussTaps taps;
     memset(&taps, 0, sizeof(taps));
     gaussian1d(gaussian_size, taps.k);
     lg_launch_smooth(depth, out, B, H, W, gaussian_size, taps, (hipStream_t)stream_);
-    LG_HIP(h, hipGetLastError());
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_create_err = std::string("lg_smooth_depth: ") + hipGetErrorString(e); return LG_ERR_HIP; }
     return LG_OK;
 }
 
@@ -861,7 +881,7 @@ int lg_leaf_stats(lg_handle h, const int16_t* labels, const float* depth, int H,
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
     ProfScope ps(h, "leaf", s);
-    int rc = lg_leaf_run(h->leaf, labels, depth, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, s, h->s_dt[0], &err);
+    int rc = lg_leaf_run(h->leaf, labels, depth, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, s, h->s_dt[0], &err, h->leaf_prof);
     if (rc) return fail(h, rc, err.c_str());
     return LG_OK;
 }
@@ -878,7 +898,7 @@ int lg_leaf_stats_batch(lg_handle h, const int16_t* labels, const float* depth, 
     std::string err;
     ProfScope ps(h, "leaf", s);
     int rc = lg_leaf_run_batch(h->leaf, labels, depth, B, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, status, s,
-                               h->s_dt[0], &err);
+                               h->s_dt[0], &err, h->leaf_prof);
     if (rc) return fail(h, rc, err.c_str());
     return LG_OK;
 }
@@ -895,7 +915,7 @@ int lg_leaf_select_batch(lg_handle h, const int16_t* labels, const float* depth,
     ProfScope ps(h, "leaf", s);
     int rc;
     try {   // (the host half allocates: nothing may throw across the C boundary)
-        rc = lg_leaf_select_batch_run(h->leaf, labels, depth, B, H, W, cx, cy, f, ids, n_tall, tall, tall_cap, s, h->s_dt[0], &err);
+        rc = lg_leaf_select_batch_run(h->leaf, labels, depth, B, H, W, cx, cy, f, ids, n_tall, tall, tall_cap, s, h->s_dt[0], &err, h->leaf_prof);
     } catch (const std::bad_alloc&) {
         return fail(h, LG_ERR_NOMEM, "lg_leaf_select_batch: out of host memory");
     } catch (...) {

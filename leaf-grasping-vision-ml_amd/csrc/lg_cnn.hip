@@ -1174,9 +1174,9 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const f
 }
 
 #define LG_WINO4_L0_SHAPES(X) X(12, 64, 32, false) X(12, 128, 32, false)
-int g_wino4_cus = 0;   // > 0: workgroups (= CUs) the persistent F(4x4) kernels may take (set per call from LgCnn::max_cus; experiment)
+// max_cus > 0: workgroups (= CUs) the persistent F(4x4) kernels may take (LgCnn::max_cus, the LG_CNN_CUS experiment)
 bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
-                     float* out, int N, hipStream_t s) {
+                     float* out, int N, int max_cus, hipStream_t s) {
     const int tp = (wi / 4) * (wi / 4);
     const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
     // persistent: one 512-thread workgroup per CU (140-156 KB of LDS each), a multiple of 8 so every XCD gets the same number
@@ -1186,7 +1186,7 @@ bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const 
         return n >= 8 ? n / 8 * 8 : 8;
     }();
     const long long items8 = (long long)((ntb + 7) / 8) * (cout / 64);   // items per XCD
-    const int cus = g_wino4_cus > 0 ? std::max(8, std::min(num_cu, g_wino4_cus / 8 * 8)) : num_cu;
+    const int cus = max_cus > 0 ? std::max(8, std::min(num_cu, max_cus / 8 * 8)) : num_cu;
     const int grid = 8 * (int)std::min<long long>(items8, cus / 8);
 #define X(CI, CO, W_, P)                                                                                              \
     if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
@@ -1442,7 +1442,6 @@ int lg_cnn_run(LgCnn* c, const float* patches, bool haloed_in, int N, float* log
 static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err) {
     int rc = ensure_act(c, N, s, err);
     if (rc) return rc;
-    g_wino4_cus = c->max_cus;
     const float* x = patches;
     if (!haloed_in) {   // the C-ABI's dense [N][9][32][32] patches -> haloed planes
         hipLaunchKernelGGL(lg_repack_kernel, dim3((unsigned)(N * 9)), dim3(256), 0, s, patches, c->in_halo, (long long)N * 9);
@@ -1450,7 +1449,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
     }
     // layer 0: the F(4x4,3x3) kernel on 12 input planes (3 chunks); the direct 9-channel kernel with LG_CNN_DIRECT / _F23 / mask bit 0 clear
     if (!c->use_f23 && (c->wino_mask & 1) &&
-        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, s)) {
+        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, c->max_cus, s)) {
         // (a shape the F(4x4) table lacks falls through to the direct kernel instead of leaving act[0] unwritten)
     } else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
     else launch_conv0<128>(x, c, c->act[0], N, s);
@@ -1462,7 +1461,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         const RtLayer& l = c->layers[L];                                                                            \
         if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, c->act[L], N, s);                               \
         else if (c->use_f23) launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
-        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, s); \
+        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, s); \
         cur = c->act[L];                                                                                            \
     } while (0)
         LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
@@ -1475,7 +1474,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         for (int L = 1; L < c->n_layers; L++) {
             const RtLayer& l = c->layers[L];
             const bool okl = c->use_f23 ? launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)
-                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, s);
+                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, s);
             if (!okl) {
                 *err = "lg_cnn_forward: unsupported layer shape";
                 return LG_ERR_UNSUPPORTED;

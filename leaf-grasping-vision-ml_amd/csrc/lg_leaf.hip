@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
+#include <string>
 #include <vector>
 
 #define LGL_GROUP 64         // slots per LDS histogram group
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
                 const double v = dx * dx + dy * dy + f2;
                 const float r0 = __builtin_amdgcn_sqrtf((float)v);
                 const double rd = (double)r0;
-                if (!(ablate & 4)) sr += rd + (v - rd * rd) * (double)(0.5f * __frcp_rn(r0));
+                if (!(ablate & 4)) sr += r0 > 0.0f ? rd + (v - rd * rd) * (double)(0.5f * __frcp_rn(r0)) : 0.0;   // (v == 0: f == 0 and the pixel is the optical centre)
                 bd |= (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
                 const unsigned key = f2key(dv[k]);
                 kmx = max(kmx, key); nkmn = max(nkmn, ~key);
@@ -916,6 +918,63 @@ __global__ __launch_bounds__(256) void k_rowbest(const unsigned long long* __res
 
 }  // namespace
 
+// ---- per-kernel timing (event pairs on the launching stream, resolved after the call's synchronise)
+struct LgLeafProf {
+    struct Slot { std::string name; std::vector<hipEvent_t> ev; size_t used = 0; int launches = 0; double ms = 0.0; };
+    bool on = false;
+    std::vector<Slot> slots;
+};
+LgLeafProf* lg_leaf_prof_new() { return new (std::nothrow) LgLeafProf(); }
+void lg_leaf_prof_free(LgLeafProf* p) {
+    if (!p) return;
+    for (auto& sl : p->slots)
+        for (auto e : sl.ev) hipEventDestroy(e);
+    delete p;
+}
+void lg_leaf_prof_enable(LgLeafProf* p, int on) {
+    if (!p) return;
+    p->on = on != 0;
+    for (auto& sl : p->slots) { sl.used = 0; sl.launches = 0; sl.ms = 0.0; }
+}
+static void leaf_prof_flush(LgLeafProf* p) {
+    if (!p) return;
+    for (auto& sl : p->slots) {
+        for (size_t i = 0; i + 1 < sl.used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sl.ev[i], sl.ev[i + 1]) == hipSuccess) { sl.ms += ms; sl.launches++; }
+        }
+        sl.used = 0;
+    }
+}
+int lg_leaf_prof_read(LgLeafProf* p, const char* name, int* launches, double* total_ms) {
+    if (!p || strncmp(name, "leaf_", 5) != 0) return 0;
+    for (auto& sl : p->slots)
+        if (sl.name == name) { if (launches) *launches = sl.launches; if (total_ms) *total_ms = sl.ms; return 1; }
+    return 1;
+}
+namespace {
+struct LeafProfScope {   // an event pair around the launches of its scope
+    hipEvent_t e1 = nullptr;
+    hipStream_t s;
+    LeafProfScope(LgLeafProf* p, const char* name, hipStream_t s_) : s(s_) {
+        if (!p || !p->on) return;
+        LgLeafProf::Slot* sl = nullptr;
+        for (auto& x : p->slots)
+            if (x.name == name) sl = &x;
+        if (!sl) { p->slots.emplace_back(); sl = &p->slots.back(); sl->name = name; }
+        if (sl->used + 2 > sl->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            sl->ev.push_back(a); sl->ev.push_back(b);
+        }
+        hipEventRecord(sl->ev[sl->used], s);
+        e1 = sl->ev[sl->used + 1];
+        sl->used += 2;
+    }
+    ~LeafProfScope() { if (e1) hipEventRecord(e1, s); }
+};
+}  // namespace
+
 struct LgLeafWs {   // every array holds capB frames back to back
     unsigned long long* pres;  // 512
     int* pre;                  // 512
@@ -1037,7 +1096,7 @@ static int leaf_edt_fallback(LgLeafWs* w, const int16_t* labels, int B, int H, i
 // host round trip between the passes (the median ranks are seeded on the device), one copy-back at the end.
 int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, float cx, float cy,
                       float f, lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, int* status,
-                      hipStream_t s, hipStream_t side, std::string* err) {
+                      hipStream_t s, hipStream_t side, std::string* err, LgLeafProf* prof) {
     int rc = leaf_ws(w, B, H, W);
     if (rc) { *err = "lg_leaf_stats: workspace allocation failed"; return rc; }
     if (W > 4096 || H > 65535) { *err = "lg_leaf_stats: width > 4096 unsupported"; return LG_ERR_UNSUPPORTED; }
@@ -1058,23 +1117,36 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     hipMemsetAsync(w->first_leaf, 0xFF, nb * 8, s);
     hipMemsetAsync(w->above, 0xFF, nb * 4 * LGL_MAXL, s);
     hipMemsetAsync(w->maxpass, 0, nb * 4, s);
-    hipLaunchKernelGGL(k_presence_bits, grid, dim3(256), 0, s, labels, depth, H, W, WW, w->pres, w->bits, w->first_leaf);
+    {
+        LeafProfScope ps(prof, "leaf_presence", s);
+        hipLaunchKernelGGL(k_presence_bits, grid, dim3(256), 0, s, labels, depth, H, W, WW, w->pres, w->bits, w->first_leaf);
+    }
     // clutter extrema: needs only the bit mask; runs beside the statistics chain on a second stream of the handle
     // (side = one of the handle's own streams: a stream more per process changes how ROCm maps streams to its few hardware
     //  queues -- an extra stream here made an unrelated trainer in the same process 2.5x slower)
     hipStream_t s2 = side ? side : s;
     hipEventRecord(w->ev_in, s);
     hipStreamWaitEvent(s2, w->ev_in, 0);
-    hipLaunchKernelGGL(k_rowocc, dim3(std::max(4, std::min(64, 2048 / B)), B), dim3(256), 0, s2, w->bits, H, WW, w->occ);
-    hipLaunchKernelGGL(k_edt_bb, dim3(B), dim3(LGL_BB_T), 0, s2, w->bits, w->occ, H, W, WW, w->qa, w->qb, w->best, w->bbflag);
+    {
+        LeafProfScope ps(prof, "leaf_edt", s2);
+        hipLaunchKernelGGL(k_rowocc, dim3(std::max(4, std::min(64, 2048 / B)), B), dim3(256), 0, s2, w->bits, H, WW, w->occ);
+        hipLaunchKernelGGL(k_edt_bb, dim3(B), dim3(LGL_BB_T), 0, s2, w->bits, w->occ, H, W, WW, w->qa, w->qb, w->best, w->bbflag);
+    }
     hipEventRecord(w->ev_side, s2);
     hipLaunchKernelGGL(k_prefix, dim3(B), dim3(64), 0, s, w->pres, w->pre, w->nlab);
-    hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc, w->comp, w->comp_n, comp_stride, segcap, ablate);
+    {
+        LeafProfScope ps(prof, "leaf_accumulate", s);
+        hipLaunchKernelGGL(k_accumulate, grid, dim3(256), 0, s, labels, depth, H, W, w->pres, w->pre, cx, cy, f, w->acc, w->comp, w->comp_n, comp_stride, segcap, ablate);
+    }
     // exact medians: ranks from the areas, 4 radix passes over the leaf-pixel list, successor for even counts
     hipLaunchKernelGGL(k_seed, dim3(LGL_MAXL / 256, B), dim3(256), 0, s, w->acc, w->st, w->maxpass);
     for (int pass = 3; pass >= 0; pass--) {
-        hipLaunchKernelGGL(k_hist<16>, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, w->maxpass, pass, w->hist,
-                           w->above, ablate);
+        {
+            LeafProfScope ps(prof, "leaf_hist", s);
+            hipLaunchKernelGGL(k_hist<16>, grid, dim3(256), 0, s, w->comp, w->comp_n, comp_stride, segcap, w->nlab, w->st, w->maxpass, pass, w->hist,
+                               w->above, ablate);
+        }
+        LeafProfScope ps(prof, "leaf_select", s);
         hipLaunchKernelGGL(k_select, dim3(16, B), dim3(256), 0, s, w->st, w->hist, w->nlab, w->maxpass, pass, w->above, w->succ);
     }
     hipStreamWaitEvent(s, w->ev_side, 0);   // join: `best` is read back below
@@ -1100,6 +1172,7 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
         *err = "lg_leaf_stats: device copy / kernel failed";
         return LG_ERR_HIP;
     }
+    if (prof && prof->on) leaf_prof_flush(prof);
     bool any_flag = false;
     for (int b = 0; b < B; b++) any_flag |= w->h_hdr[b].bbflag != 0;
     if (any_flag) {   // a survivor list overflowed somewhere: the full-transform pass for the batch, then the headers once more
@@ -1229,12 +1302,12 @@ int lg_leaf_select_host(const lg_leaf_stat* st, int n, const int32_t ext[4], int
 // statistics + selection for B frames, results only: ids [B] (-1 none, -2 "use the Python path"), n_tall [B], tall [B][tall_cap]
 int lg_leaf_select_batch_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int B, int H, int W, double cx, double cy,
                              double f, int32_t* ids, int32_t* n_tall, int32_t* tall, int tall_cap, hipStream_t s, hipStream_t side,
-                             std::string* err) {
+                             std::string* err, LgLeafProf* prof) {
     const int cap = 256;   // result rows per frame of this entry point (frames with more labels: -2, the caller's general path)
     std::vector<lg_leaf_stat> stats((size_t)B * cap);
     std::vector<int> nl(B), status(B);
     std::vector<int32_t> ext((size_t)B * 4);
-    int rc = lg_leaf_run_batch(w, labels, depth, B, H, W, (float)cx, (float)cy, (float)f, stats.data(), cap, nl.data(), ext.data(), status.data(), s, side, err);
+    int rc = lg_leaf_run_batch(w, labels, depth, B, H, W, (float)cx, (float)cy, (float)f, stats.data(), cap, nl.data(), ext.data(), status.data(), s, side, err, prof);
     if (rc) return rc;
     for (int b = 0; b < B; b++) {
         n_tall[b] = 0;
@@ -1248,6 +1321,6 @@ int lg_leaf_select_batch_run(LgLeafWs*& w, const int16_t* labels, const float* d
 
 int lg_leaf_run(LgLeafWs*& w, const int16_t* labels, const float* depth, int H, int W, float cx, float cy, float f,
                 lg_leaf_stat* stats, int max_leaves, int* n_leaves, int32_t* extrema, hipStream_t s, hipStream_t side,
-                std::string* err) {
-    return lg_leaf_run_batch(w, labels, depth, 1, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, nullptr, s, side, err);
+                std::string* err, LgLeafProf* prof) {
+    return lg_leaf_run_batch(w, labels, depth, 1, H, W, cx, cy, f, stats, max_leaves, n_leaves, extrema, nullptr, s, side, err, prof);
 }

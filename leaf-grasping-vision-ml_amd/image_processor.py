@@ -57,10 +57,22 @@ def gaussian_config(image_processor):
 def flatness_config(image_processor):
     """Gaussian size of the smoothing `_calculate_flatness_map` (grasp_point_selector.py:635-657) applies with this
     ImageProcessor; the gradient kernels it reads from the same object must be the reference's Sobel pair."""
+    # checked once per object and set of kernel tensors (select_grasp_point calls this on its latency path: three get_kernel
+    # calls, an allclose and a library call per frame otherwise)
+    ks = getattr(image_processor, "kernels", None)
+    key = tuple(id(ks.get(n)) for n in ("gaussian", "sobel_x", "sobel_y")) if isinstance(ks, dict) else None
+    cached = getattr(image_processor, "_lg_flatness_config", None)
+    if key is not None and cached is not None and cached[0] == key:
+        return cached[1]
     size = gaussian_config(image_processor)
     sx, sy = _kernel(image_processor, "sobel_x"), _kernel(image_processor, "sobel_y")
     if sx.shape != (3, 3) or not np.array_equal(sx, np.array(_SOBEL_X)) or not np.array_equal(sy, np.array(_SOBEL_X).T):
         raise ValueError("image_processor carries gradient kernels other than the 3x3 Sobel pair: unsupported")
+    if key is not None:
+        try:
+            image_processor._lg_flatness_config = (key, size)
+        except Exception:  # noqa: BLE001   (an object that takes no attributes: checked every time)
+            pass
     return size
 
 
@@ -121,6 +133,7 @@ class ImageProcessor:
         index = dev.index if dev.index is not None else torch.cuda.current_device()
         with torch.cuda.device(dev):
             h = _handle(index)
-            check(h, lib.lg_smooth_depth(h, d.data_ptr(), 1, H, W, size, out.data_ptr(),
-                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lg_smooth_depth")
+            # (stateless in the library: the shared per-device handle is only read; a failure's reason is per thread)
+            check(None, lib.lg_smooth_depth(h, d.data_ptr(), 1, H, W, size, out.data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lg_smooth_depth")
         return out.squeeze()

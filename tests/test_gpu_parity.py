@@ -728,8 +728,11 @@ def test_second_thread_on_a_busy_handle_is_refused(L):
 
     def run():
         inside.set()
-        for _ in range(4):
-            got.append(s.select_grasp_points_batch(m, d))
+        while len(got) < 4:
+            try:
+                got.append(s.select_grasp_points_batch(m, d))
+            except _lib.LgError as e:   # the poller was inside the handle when this call arrived: the rule cuts both ways
+                assert "another thread" in str(e)
     th = threading.Thread(target=run)
     th.start()
     inside.wait()
@@ -870,6 +873,39 @@ def test_pcl_data_ends_in_the_logged_none_triple(sel):
     assert sel.select_grasp_point(m, d, None)[0] is not None
     assert sel.select_grasp_point(m, d, None, pcl_data=np.zeros((H * W, 3), np.float32)) == (None, None, None)
     assert sel.select_grasp_point(m, d, None, pcl_data=[]) == (None, None, None)
+
+
+def test_orientation_scratch_failure_hands_over_to_the_host_analysis(L, monkeypatch):
+    """when the device-side contour scratch cannot be set up the call goes on with the host analysis of every frame --
+    the failed allocation's (sticky) HIP error must not fail that very call, and the reason is readable (lg_orientation_note)."""
+    from leafgrasp_amd._lib import lib
+    H, W = 270, 360
+    labels, depth, P = O.synthetic_scene(H, W, 1)
+    m, d = torch.from_numpy(labels == 1).cuda(), torch.from_numpy(depth).cuda()
+    ok = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    ok.set_camera_params(P)
+    exp = ok.select_grasp_point(m, d, None)
+    assert lib.lg_orientation_note(ok._h) == b""
+    monkeypatch.setenv("LG_ORIENT_FAIL", "1")
+    s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    s.set_camera_params(P)
+    got = s.select_grasp_point(m, d, None)           # the FIRST call after the failed set-up
+    monkeypatch.delenv("LG_ORIENT_FAIL")
+    assert got[0] is not None and got == exp
+    assert b"LG_ORIENT_FAIL" in lib.lg_orientation_note(s._h)
+    a1, a2 = ok.estimate_leaf_orientation((labels == 1).astype(np.uint8)), s.estimate_leaf_orientation((labels == 1).astype(np.uint8))
+    assert a1 == a2 and a1[0] is not None
+
+
+def test_gaussian_larger_than_the_frame_ends_in_the_none_triple(L):
+    """torch's reflect padding refuses size // 2 >= min(H, W) ("Padding size should be less than the corresponding input
+    dimension"): the reference ends in its logged None triple (grasp_point_selector.py:635-657, :251-253)."""
+    s = L.GraspPointSelector(torch.device("cuda:0"), load_model=False)
+    s.set_camera_params(O.synthetic_scene(64, 64, 0)[2])
+    H, W = 8, 3
+    m = torch.ones((H, W), dtype=torch.bool).cuda()
+    d = torch.full((H, W), 0.5).cuda()
+    assert s.select_grasp_point(m, d, L.ImageProcessor(H, W, 21, 7)) == (None, None, None)
 
 
 def test_uint8_mask_with_255_values(sel):
