@@ -46,7 +46,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LG_W4_EXP 0   // timing ablations of lg_wino4_kernel (WRONG RESULTS): 1 no transform arithmetic, 2 no transform at all,
 #endif                //   4 no A DMA, 8 no input DMA, 16 no fragment reads, 32 no MFMAs, 64 no epilogue, 128 no halo stores (right results),
                       //   256 epilogue arithmetic without its stores, 512 stores into one small region,
-                      //   2048 / 4096 no stores from the staging / the transform waves, 8192 half the fragment reads (B operand stale)
+                      //   2048 / 4096 no stores from the staging / the transform waves, 8192 half the fragment reads (B operand stale),
+                      //   16384 / 32768 the transform without its LDS reads / writes
 
 namespace {
 
@@ -582,8 +583,16 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     constexpr int TROWS = TPB / TC;                        // tile rows per band
     constexpr int WP = lg_wp(WI), PLANE = lg_plane(WI);
     constexpr int RH = 4 * TROWS + 2;                      // staged haloed rows per channel and patch
-    constexpr int RS = RH * WP, S = PB * RS;
+    // LDS image of the staged rows.  Row pitch WPL: the transform reads a lane's tile rows as 16-byte pieces, lane = (channel
+    // bit, tile), and with the planes' own pitch (WI + 4) every such read took 8 LDS cycles instead of 4 -- bank conflicts, 90 % of
+    // the kernel's conflict cycles (tools/ubench/lds_conflict.hip, profiles/r04_ubench_lds_conflicts.txt: which lane -> address
+    // patterns a ds_read_b128 takes at full rate is not the textbook rule; measured).  32 x 32 images: pitch 40, 16 x 16: 24 are
+    // conflict-free; 8 x 8 keeps pitch 12 and deals the wave's 8-lane groups to the tiles in the order 0 1 3 2 (tperm below).
+    // The pad pieces of a row are slots of the DMA enumeration that fetch a harmless valid address.
+    constexpr int WPL = WI == 32 ? 40 : WI == 16 ? 24 : WP;
+    constexpr int RS = RH * WPL, S = PB * RS;
     constexpr int PPC = RS / 4;
+    constexpr int RPC = WPL / 4, RPV = WP / 4;             // 16-byte slots per LDS row, of which the first RPV hold data
     constexpr int NPIECE = KC * PB * PPC;
     constexpr int NIN = (NPIECE + 255) / 256;              // input transfers per chunk and thread of the four staging waves
     constexpr int STAGE = NIN * 256 * 4;                   // floats per input stage
@@ -663,8 +672,9 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                 const int e = (j * 4 + dw) * 64 + lane;
                 const int ci = e / (PB * PPC), r = e % (PB * PPC);
                 const int pb = r / PPC, piece = r % PPC;
-                const bool ok = e < NPIECE && nb + pb < N;
-                voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + y0 * WP + 4 * piece) : 0u;
+                const int prow = piece / RPC, pcol = piece % RPC;
+                const bool ok = e < NPIECE && nb + pb < N && pcol < RPV;
+                voff[j] = ok ? 4u * (unsigned)((pb * CIN + ci) * PLANE + (y0 + prow) * WP + 4 * pcol) : 0u;
             }
         };
         // transfer j of the input chunk the stream points at (then the stream advances after the last one)
@@ -690,17 +700,25 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 
         // ---- transform state (waves 0..3): channel tk, tile tau, half th (rows 3 th .. 3 th + 2 of V)
         const int th = wave & 1;
-        const int tk = ((wave >> 1) << 1) | (lane >> 5), tau = lane & 31;
-        const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WP + 4 * ((tau % TPB) % TC) + th * WP;  // half 1 starts at row 1
+        // (8 x 8 images: the 8-lane groups 2 and 3 of each half-wave swap their tiles -- see WPL above)
+        const int tk = ((wave >> 1) << 1) | (lane >> 5), tau = WI == 8 ? ((lane & 31) ^ ((lane & 16) >> 1)) : (lane & 31);
+        const int tsrc = tk * S + (tau / TPB) * RS + (4 * ((tau % TPB) / TC)) * WPL + 4 * ((tau % TPB) % TC) + th * WPL;  // half 1 starts at row 1
         const int tdst = (((tau >> 4) * 9) * 64 + (tk * 16 + (tau & 15))) * 4;
         // rows th .. th + 4 of the 6x6 tile (half 0 needs rows 0..4, half 1 rows 1..5)
-        auto transform_load = [&](int stage, f32x4 (&dl)[5], f32x2 (&dh)[5]) {
+        auto transform_load = [&](int stage, f32x4 (&dl)[5], f32x4 (&dh)[5]) {
             if (LG_W4_EXP & 2) return;
+            if (LG_W4_EXP & 16384) {   // ablation: the transform without its LDS reads
+#pragma unroll
+                for (int q = 0; q < 5; q++) { dl[q] = (f32x4){1.f, 2.f, 3.f, (float)lane}; dh[q] = (f32x4){4.f, (float)stage, 0.f, 0.f}; asm volatile("" : "+v"(dl[q]), "+v"(dh[q])); }
+                return;
+            }
             const float* sp = s_in + stage * STAGE + tsrc;
 #pragma unroll
             for (int q = 0; q < 5; q++) {
-                dl[q] = *reinterpret_cast<const f32x4*>(sp + q * WP);      // 16-byte aligned: tile columns start at multiples of 4
-                dh[q] = *reinterpret_cast<const f32x2*>(sp + q * WP + 4);
+                dl[q] = *reinterpret_cast<const f32x4*>(sp + q * WPL);      // 16-byte aligned: tile columns start at multiples of 4
+                // columns 4..5 of the tile, read as 16 bytes (columns 6..7 lie inside the row: WP = WI + 4): an 8-byte read with a
+                // 16-byte lane stride takes the same 4 LDS cycles and counts 2 of them as bank conflict
+                dh[q] = *reinterpret_cast<const f32x4*>(sp + q * WPL + 4);
             }
         };
         auto col6 = [](const float (&r)[6], float (&v)[6]) {   // 1-D transform B^T of a 6-vector (12 VALU)
@@ -711,8 +729,12 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             v[3] = fmaf(2.f, e, cc); v[4] = fmaf(-2.f, e, cc);
             v[5] = fmaf(4.f, r[1], fmaf(-5.f, r[3], r[5]));
         };
-        auto transform_store = [&](int vstage, const f32x4 (&dl)[5], const f32x2 (&dh)[5]) {
+        auto transform_store = [&](int vstage, const f32x4 (&dl)[5], f32x4 (&dh)[5]) {
             if (LG_W4_EXP & 2) return;
+            // (all four floats of dh count as used: hipcc otherwise narrows those loads to ds_read2_b64 / ds_read_b64 -- the 8-byte
+            //  reads whose bank conflicts the 16-byte form avoids; here, where the values are consumed, not at the loads)
+#pragma unroll
+            for (int q = 0; q < 5; q++) asm("" : "+v"(dh[q]));
             float* g0 = s_v + vstage * VBLK + tdst;             // lane (k, tau & 15) of tile block tau >> 4; position p at (p >> 2) * 256 + (p & 3)
             auto D = [&](int q, int j) { return j < 4 ? dl[q][j & 3] : dh[q][j & 1]; };
             float r[3][6];
@@ -745,6 +767,11 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             for (int i = 0; i < 3; i++)
 #pragma unroll
                 for (int j = 0; j < 6; j++) asm("" : "+v"(v[i][j]));
+            if (LG_W4_EXP & 32768) {   // ablation: the transform without its LDS writes
+#pragma unroll
+                for (int i = 0; i < 3; i++) asm volatile("" ::"v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]), "v"(v[i][4]), "v"(v[i][5]));
+                return;
+            }
             if (th == 0) {      // positions 0..17
                 *reinterpret_cast<f32x4*>(g0) = (f32x4){v[0][0], v[0][1], v[0][2], v[0][3]};
                 *reinterpret_cast<f32x4*>(g0 + 256) = (f32x4){v[0][4], v[0][5], v[1][0], v[1][1]};
@@ -774,7 +801,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (IS_T) {
             f32x4 dl[5];
-            f32x2 dh[5];
+            f32x4 dh[5];
             transform_load(0, dl, dh);
             transform_store(0, dl, dh);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -845,7 +872,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     __builtin_amdgcn_sched_barrier(0)   /* hipcc moves register-only instructions across asm statements, the barrier included */
                 if (IS_T) {
                     f32x4 dl[5];
-                    f32x2 dh[5];
+                    f32x4 dh[5];
                     transform_load(in_next, dl, dh);             // (after the very last chunk: stale bytes into an unused V stage)
                     lg_lds_wait2<4>(fa[0], fb[0]); LG_MM(0);
                     LG_FRAG(3);
