@@ -509,9 +509,14 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
         LG_HIP(h, hipEventRecord(h->ev_orient, h->copy_stream));
     }
     if (h->opt_side_tail) {   // beside the sweeps (latency bound, two workgroups per CU), not behind them: 0.3 ms per 256 frames;
-        // LG_SIDE_TAIL=2 puts them on a third stream, so that orientation -> border -> stem is not one chain as long as the
-        // sweeps themselves -- measured slower (9.76-9.94 vs 9.56-9.77 ms per step, three alternating runs): default 1
-        hipStream_t ts = (h->opt_side_tail == 2 && h->opt_subbatch == 0) ? h->s_dt[1] : h->copy_stream;
+        // LG_SIDE_TAIL=2 puts them on a third stream whatever the batch, so that orientation -> border -> stem is not one chain as
+        // long as the sweeps themselves -- measured slower at 256 frames (9.76-9.94 vs 9.56-9.77 ms per step, three alternating runs)
+        // Small batches are a chain of latencies, not of throughput: orientation (0.13 ms for one frame), border maxima (0.08) and
+        // stem bits (0.01) one behind the other on the side stream were the longest chain between the bit rows and the plane
+        // kernel of a single-frame call (0.22 ms; the row search beside them takes 0.08).  Up to 32 frames the border maxima and
+        // the stem bits go to a stream of their own (s_dt[0]; the search uses s_dt[1]).
+        const bool own_tail = h->opt_subbatch == 0 && (h->opt_side_tail == 2 || n <= 32);
+        hipStream_t ts = own_tail ? h->s_dt[0] : h->copy_stream;
         if (ts != h->copy_stream) LG_HIP(h, hipStreamWaitEvent(ts, ev_prep, 0));
         const int rc = enq_tail(h, pl, off, n, ts);
         if (rc) return rc;

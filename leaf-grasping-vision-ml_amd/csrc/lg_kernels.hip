@@ -267,27 +267,29 @@ __device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form 
     const uint32_t a = (uint32_t)max(dx, dy), b = (uint32_t)min(dx, dy);
     return 2u * b <= a ? (a - 2u * b) * LG_A5 + b * LG_C5 : (a - b) * LG_C5 + (2u * b - a) * LG_B5;
 }
-// One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).
-__global__ __launch_bounds__(256) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
-                                                      int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit) {
+// One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).  1024 threads, four per
+// row (words q, q + 4, ...: the four read 32 adjacent bytes): a thread's loads are a dependent chain, and with one thread per
+// row and 256 threads the kernel took 44 us for ONE frame -- 6 % of a single-frame call.
+__global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
+                                                       int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit) {
     __shared__ int s_b[5];
     const int frame = blockIdx.x, t = threadIdx.x;
     if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; s_b[4] = 0; }
     __syncthreads();
     const unsigned long long* fb = bits + (size_t)frame * H * WW;
     int x0 = INT_MAX, x1 = -1, y0 = INT_MAX, y1 = -1, cnt = 0;
-    for (int y = t; y < H; y += 256) {
+    for (int y = t >> 2; y < H; y += 256) {
         const unsigned long long* row = fb + (size_t)y * WW;
-        int first = -1, last = -1;
-        for (int w = 0; w < WW; w++) {
+        int first = INT_MAX, last = -1;
+        for (int w = t & 3; w < WW; w += 4) {
             const unsigned long long v = row[w];
             if (v) {
-                if (first < 0) first = 64 * w + __builtin_ctzll(v);
-                last = 64 * w + 63 - __builtin_clzll(v);
+                first = min(first, 64 * w + __builtin_ctzll(v));
+                last = max(last, 64 * w + 63 - __builtin_clzll(v));
                 cnt += __popcll(v);
             }
         }
-        if (first >= 0) { x0 = min(x0, first); x1 = max(x1, last); y0 = min(y0, y); y1 = max(y1, y); }
+        if (last >= 0) { x0 = min(x0, first); x1 = max(x1, last); y0 = min(y0, y); y1 = max(y1, y); }
     }
     if (x1 >= 0) {
         atomicMin(&s_b[0], x0); atomicMax(&s_b[1], x1);
@@ -340,7 +342,7 @@ void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, in
     // B * area^1.5 <= LG_SEARCH_BUDGET * rows.  LG_DT_SEARCH_LIMIT=<x> replaces LG_SEARCH_BUDGET / B (experiments).
     static const float env_limit = getenv("LG_DT_SEARCH_LIMIT") ? (float)atof(getenv("LG_DT_SEARCH_LIMIT")) : 0.0f;
     const float limit = env_limit > 0.0f ? env_limit : LG_SEARCH_BUDGET / (float)(B > 0 ? B : 1);
-    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(256), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit);
+    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(1024), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit);
 }
 
 // ============================================================================ max d_out outside the sweep window
