@@ -488,7 +488,7 @@ def main():
             # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note,
             # + WRITE_SIZE), recorded per pixel in profiles/ by tools/pmc_final.sh; scaled to this launch.
             traffic, traffic_file = None, None
-            for cand in ("r03_pmc_counters.json", "r02_pmc_counters.json"):
+            for cand in ("r04_pmc_counters.json", "r03_pmc_counters.json", "r02_pmc_counters.json"):
                 try:
                     with open(os.path.join(REPO, "profiles", cand)) as fpmc:
                         traffic = round(json.load(fpmc)["lg_final_kernel_summary"]["traffic_bytes_per_px"] * px)

@@ -350,7 +350,7 @@ int lg_create(int device, lg_handle* out) {
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
     if (const char* e = getenv("LG_DT_SEARCH")) h->opt_dt_search = std::max(0, std::min(2, atoi(e)));
-    if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(4, atoi(e)));
+    if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(5, atoi(e)));
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LG_CNN_CUS")) {
         const int n = atoi(e);

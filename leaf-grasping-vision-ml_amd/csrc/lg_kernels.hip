@@ -952,8 +952,9 @@ __global__ __launch_bounds__(256) void lg_dtsearch_kernel(const unsigned long lo
 //                       [anchor above's row, anchor below's row] -- a dozen rows where the nearest edge stays on one side,
 //                       the leaf's whole thickness where the band crosses its medial axis (once per column).
 // ~5x fewer candidate evaluations than the one-level search at the benchmark's leaf size; same integers.
-template <int NP>   // anchor rows per lane (8 rows apart): 4 shares every candidate row's load among four pixels (large batches);
-                    // 1 gives four times the waves and a quarter of the work per wave (small batches: latency)
+template <int NP, int ST>   // NP anchor rows per lane, ST rows apart: NP = 4 shares every candidate row's load among four pixels
+                            // (large batches); 1 gives four times the waves and a quarter of the work per wave (small batches:
+                            // latency).  ST = 8: anchors of lg_dtband_kernel; ST = 32 (NP = 1): of the refinement ladder
 __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long long* __restrict__ bits,
                                                           const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
                                                           float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
@@ -964,27 +965,27 @@ __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long lo
     if (!w.search_in) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wxe = min(W, w.wx0 + w.nw * wc);
-    constexpr int ROWS = 32 * NP;   // rows per workgroup tile: four waves x NP anchors x 8
+    constexpr int ROWS = 4 * NP * ST;   // rows per workgroup tile: four waves x NP anchors x ST
     const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + ROWS - 1) / ROWS;
     const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);   // candidate rows
     const unsigned long long* fb = bits + (size_t)frame * H * WW;
     const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
-    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;   // [H / 8][W] minimising rows
+    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;   // [H][W] minimising rows
     float* dout = dist_out + (size_t)frame * H * W;
     uint32_t mx = 0;
-    constexpr int SPAN = 4 * (NP - 1);   // the anchors lie within SPAN rows of the scan's centre
+    constexpr int SPAN = ST * (NP - 1) / 2;   // the anchors lie within SPAN rows of the scan's centre
     const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
     for (int tile = j; tile < ntile; tile += G) {
         const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
         const int wi = (w.wx0 >> 6) + txi;
-        const int x = 64 * wi + lane, ya0 = w.wy0 + ROWS * tyi + 8 * NP * wave;
+        const int x = 64 * wi + lane, ya0 = w.wy0 + ROWS * tyi + ST * NP * wave;
         if (ya0 >= w.wy1) continue;   // (wave-uniform)
         const bool xin = x < W;
         const unsigned xc = (unsigned)min(x, W - 1);
         unsigned long long rb[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const int y = ya0 + 8 * i;
+            const int y = ya0 + ST * i;
             rb[i] = fb[(unsigned)(min(y, H - 1) * WW + wi)];
             rb[i] = y < w.wy1 ? lg_readlane_u64(rb[i], 0) : 0ull;
         }
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long lo
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             best[i] = (xin && ((rb[i] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
-            arow[i] = ya0 + 8 * i;   // an off-leaf pixel is its own nearest zero pixel
+            arow[i] = ya0 + ST * i;   // an off-leaf pixel is its own nearest zero pixel
         }
         if (anyb) {
             const int c = ya0 + SPAN;   // scan outwards from here: rows c - k and c + 1 + k
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long lo
                         const LgH4 hh = lg_h4(hu[q]);
 #pragma unroll
                         for (int i = 0; i < NP; i++) {
-                            const int dy = ya0 + 8 * i - yu;
+                            const int dy = ya0 + ST * i - yu;
                             const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
                             arow[i] = v < best[i] ? yu : arow[i];
                             best[i] = min(best[i], v);
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long lo
                         const LgH4 hh = lg_h4(hv[q]);
 #pragma unroll
                         for (int i = 0; i < NP; i++) {
-                            const int dy = ya0 + 8 * i - yd;
+                            const int dy = ya0 + ST * i - yd;
                             const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
                             arow[i] = v < best[i] ? yd : arow[i];
                             best[i] = min(best[i], v);
@@ -1044,11 +1045,11 @@ __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long lo
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const int y = ya0 + 8 * i;
+            const int y = ya0 + ST * i;
             mx = max(mx, best[i]);
             if (xin && y < w.wy1) {
                 dout[(unsigned)(y * W) + xc] = (float)best[i] * (1.0f / 65536.0f);
-                argb[(unsigned)((y >> 3) * W) + xc] = (uint16_t)arow[i];
+                argb[(unsigned)(y * W) + xc] = (uint16_t)arow[i];
             }
         }
     }
@@ -1110,17 +1111,19 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
             // (row = first + t): along a tilted edge the windows of neighbouring columns are shifted against each other, and a
             // row shared by the whole wave would have to cover their union -- 64 columns x the edge's slope.  The loads are then
             // per-lane rows (neighbouring lanes mostly hit the same or the next line; seven evaluations pay for each).
-            const int a1 = argb[(unsigned)((ya >> 3) * W) + xc];
+            const int a1 = argb[(unsigned)(ya * W) + xc];
             const int yb = ya + 8;
-            const int a2 = yb <= w.by1 ? (int)argb[(unsigned)((min(yb, H - 1) >> 3) * W) + xc] : hi;
+            const int a2 = yb <= w.by1 ? (int)argb[(unsigned)(min(yb, H - 1) * W) + xc] : hi;
             const bool mine = xin && ((anyb >> lane) & 1ull);
             const int first = max(min(a1, a2), lo);
             const int len = mine ? min(max(a1, a2), hi) - first + 1 : 0;
             const int maxlen = lg_wave_max_i32(len);
             for (int t0 = 0; t0 < maxlen; t0 += 4) {
-                uint32_t hh4[4];
+                uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
+                if (t0 < len) {   // (lanes whose window has ended fetch nothing: see lg_dtrefine_kernel)
 #pragma unroll
-                for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
+                    for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const bool act = t0 + q < len;
@@ -1151,6 +1154,82 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
     if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
 }
 
+// ---- the refinement ladder: anchors every 32 rows (lg_dtanchor_kernel<1, 32>), then the rows half-way between two solved rows,
+// level by level (S = 16, 8, 4, 2, 1): the row y = ya + S between the solved rows ya and ya + 2S only looks at the candidate
+// rows between their minimisers.  ~10 evaluations per pixel instead of ~90 for the one-level search at the benchmark's leaf size
+// (the anchors 2d / 32, every level a window that halves with its spacing) -- at the price of one launch per level, which only
+// large batches can afford.  Wave = one target row x 64 columns, every lane its own window (per-lane rows, see lg_dtband_kernel).
+template <int S>
+__global__ __launch_bounds__(256) void lg_dtrefine_kernel(const unsigned long long* __restrict__ bits,
+                                                          const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
+                                                          float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
+                                                          int W, int WW, int wc, int G, int B) {
+    int frame, j;
+    if (!lg_frame_of_block(G, B, &frame, &j)) return;
+    const LgWin w = wins[frame];
+    if (!w.search_in) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wxe = min(W, w.wx0 + w.nw * wc);
+    const int ntx = (wxe - w.wx0 + 63) >> 6;
+    const int ntg = (w.wy1 - w.wy0 - S + 2 * S - 1) / (2 * S);        // target rows wy0 + S + 2 S m < wy1
+    const int nty = (max(ntg, 0) + 3) >> 2;                           // four target rows (waves) per workgroup tile
+    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);     // candidate rows
+    const unsigned long long* fb = bits + (size_t)frame * H * WW;
+    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
+    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;
+    float* dout = dist_out + (size_t)frame * H * W;
+    uint32_t mx = 0;
+    const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
+    for (int tile = j; tile < ntile; tile += G) {
+        const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
+        const int wi = (w.wx0 >> 6) + txi;
+        const int x = 64 * wi + lane, y = w.wy0 + S + 2 * S * (4 * tyi + wave);
+        if (y >= w.wy1) continue;   // (wave-uniform)
+        const bool xin = x < W;
+        const unsigned xc = (unsigned)min(x, W - 1);
+        const unsigned long long rb = lg_readlane_u64(fb[(unsigned)(y * WW + wi)], 0);
+        const bool on = xin && ((rb >> lane) & 1ull);
+        uint32_t best = on ? 0xFFFFFFFFu : 0u;
+        int arow = y;
+        if (rb) {
+            const int ya = y - S, yb = y + S;
+            const int a1 = argb[(unsigned)(ya * W) + xc];
+            const int a2 = yb <= w.by1 ? (int)argb[(unsigned)(min(yb, H - 1) * W) + xc] : hi;
+            const int first = max(min(a1, a2), lo);
+            const int len = on ? min(max(a1, a2), hi) - first + 1 : 0;
+            const int maxlen = lg_wave_max_i32(len);
+            for (int t0 = 0; t0 < maxlen; t0 += 4) {
+                // only lanes whose window reaches this group of four rows load at all: the rows are per lane (64 cache lines per
+                // wave instruction), and where a few columns cross the leaf's medial axis their long windows would otherwise make
+                // all 64 lanes fetch lines for a hundred rows -- the vector memory path, not the arithmetic, was the bound then
+                uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
+                if (t0 < len) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool act = t0 + q < len;
+                    if (__any(act && (hh4[q] << 16) < best)) {   // N(h, .) >= a * h
+                        const int yc = first + t0 + q;
+                        const int dy = y - yc;
+                        const uint32_t v = act ? lg_norm5_h(lg_h4(hh4[q]), (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
+                        arow = v < best ? yc : arow;
+                        best = min(best, v);
+                    }
+                }
+            }
+        }
+        mx = max(mx, best);
+        if (xin) {
+            dout[(unsigned)(y * W) + xc] = (float)best * (1.0f / 65536.0f);
+            if (S > 1) argb[(unsigned)(y * W) + xc] = (uint16_t)arow;
+        }
+    }
+    mx = lg_wave_max_u32(mx);
+    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
+}
+
 static int lg_search_groups(int B, int per_batch, int lo, int hi) {
     const int bpad = 8 * ((B + 7) / 8);
     return std::max(lo, std::min(hi, per_batch / bpad));
@@ -1173,14 +1252,31 @@ int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint
         hipLaunchKernelGGL(lg_dtsearch_kernel, dim3(nb8 * G), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, G, B);
         return 1;
     }
+    if (algo == 5) {   // the ladder: anchors every 32 rows, then levels 16, 8, 4, 2, 1
+        const int tiles32 = ((W + 63) / 64) * ((H + 127) / 128);
+        if (phase == 0) {
+            const int Ga = g_env > 0 ? g_env : std::min(tiles32, lg_search_groups(B, 16384, 8, 512));
+            hipLaunchKernelGGL((lg_dtanchor_kernel<1, 32>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+            return 1;
+        }
+#define LG_REFINE(S_)                                                                                                          \
+    {                                                                                                                          \
+        const int tl = ((W + 63) / 64) * ((H + 8 * (S_) - 1) / (8 * (S_)));                                                    \
+        const int Gr = g_env > 0 ? g_env : std::min(tl, lg_search_groups(B, 32768, 8, 512));                                   \
+        hipLaunchKernelGGL(lg_dtrefine_kernel<S_>, dim3(nb8 * Gr), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Gr, B); \
+    }
+        LG_REFINE(16) LG_REFINE(8) LG_REFINE(4) LG_REFINE(2) LG_REFINE(1)
+#undef LG_REFINE
+        return 1;
+    }
     if (phase == 0) {
         const bool np4 = algo == 3 || (algo == 2 && B >= 128);   // (32 frames: 0.071 vs 0.100 ms with one / four anchors per lane)
         // workgroups per frame: the window's tiles (64 columns x 128 / 32 rows) when the grid allows -- leaf tiles cluster, and a
         // workgroup that walks several of them with a fixed stride gets several heavy ones or none
         const int tiles = ((W + 63) / 64) * ((H + (np4 ? 127 : 31)) / (np4 ? 128 : 32));
         const int Ga = g_env > 0 ? g_env : std::min(tiles, lg_search_groups(B, 16384, 8, 512));
-        if (np4) hipLaunchKernelGGL(lg_dtanchor_kernel<4>, dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
-        else hipLaunchKernelGGL(lg_dtanchor_kernel<1>, dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+        if (np4) hipLaunchKernelGGL((lg_dtanchor_kernel<4, 8>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+        else hipLaunchKernelGGL((lg_dtanchor_kernel<1, 8>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
         return 1;
     }
     const int Gb = g_env > 0 ? g_env : std::min(((W + 63) / 64) * ((H + 31) / 32), lg_search_groups(B, 32768, 8, 512));

@@ -117,3 +117,34 @@ def test_anchor_and_band_search_with_arbitrary_minimisers():
                     r0, r1 = max(min(a1[x], a2[x]), lo), min(max(a1[x], a2[x]), hi)
                     got[y, x] = N(h[r0:r1 + 1, x], np.abs(np.arange(r0, r1 + 1) - y)).min()
         np.testing.assert_array_equal(got, ref)
+
+
+def test_refinement_ladder_with_arbitrary_minimisers():
+    """lg_dtanchor_kernel<1, 32> + lg_dtrefine_kernel<16 .. 1>: anchors every 32 rows, then the row half-way between two solved
+    rows from the candidate rows between their minimisers, level by level -- any minimiser at every level."""
+    rng = np.random.default_rng(11)
+    for mask in _cases(60, 2):
+        H, W = mask.shape
+        ref = O.distance_transform(mask, 5, return_fix=True)[1].astype(np.int64) * (mask > 0)
+        h, lo, hi, by0, by1 = _runs(mask)
+        rows = np.arange(lo, hi + 1)
+        wy0, wy1 = (by0 // 16) * 16, min(H, ((by1 + 16) // 16) * 16)
+        got = np.zeros_like(ref)
+        arg = {}
+
+        def solve(y, r0, r1):   # per column: minimum over candidate rows r0[x] .. r1[x], a random minimiser
+            out, a = np.zeros(W, np.int64), np.full(W, y)
+            for x in np.nonzero(mask[y])[0]:
+                rr = np.arange(r0[x], r1[x] + 1)
+                c = N(h[rr, x], np.abs(rr - y))
+                out[x] = c.min()
+                a[x] = rr[rng.choice(np.nonzero(c == c.min())[0])]
+            return out, a
+        for y in range(wy0, wy1, 32):
+            got[y], arg[y] = solve(y, np.full(W, lo), np.full(W, hi))
+        for S in (16, 8, 4, 2, 1):
+            for y in range(wy0 + S, wy1, 2 * S):
+                a1 = arg[y - S]
+                a2 = arg[y + S] if y + S <= by1 else np.full(W, hi)
+                got[y], arg[y] = solve(y, np.maximum(np.minimum(a1, a2), lo), np.minimum(np.maximum(a1, a2), hi))
+        np.testing.assert_array_equal(got, ref)
