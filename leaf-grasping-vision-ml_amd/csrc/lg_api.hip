@@ -24,9 +24,7 @@
 #include "lg_pool.h"
 
 #define LG_VERSION_STR "leafgrasp-gfx950 0.4"
-#ifndef LG_DT_ALGO_LARGE
-#define LG_DT_ALGO_LARGE 2   // row search of large batches: 2 anchors + bands, 6 LDS strips (lg_dtstrip_kernel)
-#endif
+
 
 struct LgProfSlot {
     std::string name;
@@ -353,7 +351,7 @@ int lg_create(int device, lg_handle* out) {
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
     if (const char* e = getenv("LG_DT_SEARCH")) h->opt_dt_search = std::max(0, std::min(2, atoi(e)));
-    if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(4, atoi(e)));
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LG_CNN_CUS")) {
         const int n = atoi(e);
@@ -469,10 +467,10 @@ struct Plan {  // one call's geometry, parameters and plane pointers (absolute, 
 };
 
 // which form of the row search a batch of n frames takes (LG_DT_SEARCH_ALGO forces one): one level up to 64 frames of 1080p (one
-// launch, the device is not full: 32 of 1080p 0.14 vs 0.18 ms), the ladder in LDS strips above
+// launch, the device is not full: 32 of 1080p 0.14 vs 0.18 ms), anchors + bands above (fewer evaluations: 64 of 4K 1.08 vs 1.54 ms)
 int dt_algo(const lg_ctx* h, int n, int H, int W) {
     if (h->opt_dt_algo) return h->opt_dt_algo;
-    return (long long)n * H * W <= 64ll * 1080 * 1920 ? 1 : LG_DT_ALGO_LARGE;
+    return (long long)n * H * W <= 64ll * 1080 * 1920 ? 1 : 2;
 }
 
 // frame-border maxima of d_out + stem bits: both read only the bit rows, neither is needed before the plane kernel
@@ -504,7 +502,7 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     {
         ProfScope ps(h, "bbox", s);
-        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, h->opt_dt_search, dt_algo(h, n, pl.H, pl.W), s);
+        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, h->opt_dt_search, s);
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
@@ -567,11 +565,11 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
             lg_launch_hrun(h->bits + off * words, h->tmp + 2 * off * px, h->win + off, n, pl.H, pl.W, pl.WW, ss);
         }
         const int algo = dt_algo(h, n, pl.H, pl.W);
-        for (int phase = 0; phase < (algo == 1 || algo == 6 ? 1 : 2); phase++) {
+        for (int phase = 0; phase < (algo == 1 ? 1 : 2); phase++) {
             ProfScope ps(h, phase ? "dt_band" : "dt_search", ss);
             if (lg_launch_dtsearch(phase, algo, h->bits + off * words, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
                                    h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, pl.WW, ss) < 0)
-                return fail(h, LG_ERR_HIP, "distance transform: the strip kernel's LDS request was refused");
+                return fail(h, LG_ERR_HIP, "distance transform: the search kernels could not be launched");
         }
         if (ss != s) LG_HIP(h, hipEventRecord(h->ev_search, ss));
     }
@@ -867,7 +865,7 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
     lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
     double o[5];
     if (h->orient) {   // the device analysis; a mask with more runs than its scratch holds falls through to the host code
-        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, 0, 0, s);
+        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, 0, s);
         lg_launch_orient(h->orient, h->bits, h->win, h->fp_dev, 0, 1, H, W, WW, s);
         LG_HIP(h, hipMemcpyAsync(h->orient->h_out, h->orient->out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
         LG_HIP(h, hipMemcpyAsync(h->orient->h_status, h->orient->status, sizeof(int), hipMemcpyDeviceToHost, s));

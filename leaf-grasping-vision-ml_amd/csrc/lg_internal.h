@@ -19,10 +19,7 @@
 #ifndef LG_SEARCH_BUDGET
 #define LG_SEARCH_BUDGET 1.7e7f
 #endif
-// lg_dtstrip_kernel: window rows whose run distances (rows + 2) and minimising rows (rows), 64 columns x 2 B each, plus the
-// strip's bit words fit the 160 KB of LDS
-#define LG_STRIP_ROWS 576
-#define LG_STRIP_LDS ((LG_STRIP_ROWS + 2) * 128 + LG_STRIP_ROWS * 128 + LG_STRIP_ROWS * 8)
+
 
 #define LG_MAX_GAUSS 15   // largest smoothing kernel lg_smooth_depth takes (the fused plane kernel: 1, 3, 5, 7)
 struct LgGaussTaps { float k[LG_MAX_GAUSS]; };   // 1-D factor of ImageProcessor's Gaussian (by value in the kernel arguments)
@@ -107,14 +104,12 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
 int lg_dt_geometry(int W, int* waves);
 // search_mode: 0 = d_in by the two sweeps for every frame, 1 = by the row search wherever it applies (a non-empty mask with
 // at least one zero pixel), 2 = the row search when the batch's estimated search work stays below the sweeps' latency
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, int search_algo,
-                    hipStream_t s);   // search_algo 6 (lg_dtstrip_kernel): frames whose window exceeds LG_STRIP_ROWS rows keep the sweeps
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s);
 // d_in without the row-sequential sweeps (frames with LgWin::search_in): horizontal run distances of the bounding-box rows into
 // `tmp` (the d_in half of the sweep workspace, as uint16), then the bounded search over rows, which writes distance_map inside
 // the window and the maximum into maxfix[b][0]
 void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* win, int B, int H, int W, int WW, hipStream_t s);
-// algo 1: one-level search (phase 0 only); algo 2: phase 0 = anchor rows (every 8th), phase 1 = the rows between them; 5: the
-// refinement ladder in six launches; 6: in one kernel per 64-column strip (phase 0 only)
+// algo 1: one-level search (phase 0 only); algo 2: phase 0 = anchor rows (every 8th), phase 1 = the rows between them
 int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
                        const LgWin* win, int B, int H, int W, int WW, hipStream_t s);
 int lg_launch_dt(bool bwd, const uint8_t* mask, uint32_t* tmp, float* dist_out, uint32_t* maxfix, const LgWin* win, int B,

@@ -271,8 +271,7 @@ __device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form 
 // row (words q, q + 4, ...: the four read 32 adjacent bytes): a thread's loads are a dependent chain, and with one thread per
 // row and 256 threads the kernel took 44 us for ONE frame -- 6 % of a single-frame call.
 __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
-                                                       int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit,
-                                                       int cap_rows) {
+                                                       int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit) {
     __shared__ int s_b[5];
     const int frame = blockIdx.x, t = threadIdx.x;
     if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; s_b[4] = 0; }
@@ -318,7 +317,6 @@ __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long*
             w.nw = (w.bx1 + 1 - w.wx0 + wc - 1) / wc;
             w.wy0 = (w.by0 / LG_TH) * LG_TH;
             w.wy1 = min(H, ((w.by1 + 1 + LG_TH - 1) / LG_TH) * LG_TH);
-            if (cap_rows > 0 && w.wy1 - w.wy0 > cap_rows) w.search_in = 0;   // (lg_dtstrip_kernel holds a strip's window rows in LDS)
             // Only max d_out is consumed (grasp_point_selector.py:531-533).  Inside the window d_out(p) <= N(p - q) for any leaf
             // pixel q, and both lie in the window: <= N(window width - 1, window height - 1).  At a frame corner every leaf pixel is
             // at least the corner's gap to the bounding box away in x and in y: d_out(corner) >= N(gap_x, gap_y) (N is monotone in
@@ -336,18 +334,15 @@ __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long*
     }
 }
 
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, int search_algo,
-                    hipStream_t s) {
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s) {
     int nw = 0;
     const int wc = lg_dt_geometry(W, &nw);
     // mode 2: the search's time grows like (frames in the batch) x area^1.5 -- 0.8 ms for 256 benchmark leaves of 93 k pixels --,
     // the sweeps take ~1.65 us per row of the window whatever the batch (one workgroup per frame): a frame is searched while
     // B * area^1.5 <= LG_SEARCH_BUDGET * rows.  LG_DT_SEARCH_LIMIT=<x> replaces LG_SEARCH_BUDGET / B (experiments).
     static const float env_limit = getenv("LG_DT_SEARCH_LIMIT") ? (float)atof(getenv("LG_DT_SEARCH_LIMIT")) : 0.0f;
-    // (the strip form does ~1/4 of the two-level form's instructions per pixel: four times the budget)
-    const float limit = env_limit > 0.0f ? env_limit : (search_algo == 6 ? 4.0f : 1.0f) * LG_SEARCH_BUDGET / (float)(B > 0 ? B : 1);
-    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(1024), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit,
-                       search_algo == 6 ? LG_STRIP_ROWS : 0);
+    const float limit = env_limit > 0.0f ? env_limit : LG_SEARCH_BUDGET / (float)(B > 0 ? B : 1);
+    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(1024), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit);
 }
 
 // ============================================================================ max d_out outside the sweep window
@@ -957,9 +952,9 @@ __global__ __launch_bounds__(256) void lg_dtsearch_kernel(const unsigned long lo
 //                       [anchor above's row, anchor below's row] -- a dozen rows where the nearest edge stays on one side,
 //                       the leaf's whole thickness where the band crosses its medial axis (once per column).
 // ~5x fewer candidate evaluations than the one-level search at the benchmark's leaf size; same integers.
-template <int NP, int ST>   // NP anchor rows per lane, ST rows apart: NP = 4 shares every candidate row's load among four pixels
-                            // (large batches); 1 gives four times the waves and a quarter of the work per wave (small batches:
-                            // latency).  ST = 8: anchors of lg_dtband_kernel; ST = 32 (NP = 1): of the refinement ladder
+template <int NP, int ST>   // NP anchor rows per lane, ST (= 8) rows apart: NP = 4 shares every candidate row's load among four
+                            // pixels (large batches); 1 gives four times the waves and a quarter of the work per wave (small
+                            // batches: latency)
 __global__ __launch_bounds__(256) void lg_dtanchor_kernel(const unsigned long long* __restrict__ bits,
                                                           const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
                                                           float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
@@ -1125,7 +1120,8 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
             const int maxlen = lg_wave_max_i32(len);
             for (int t0 = 0; t0 < maxlen; t0 += 4) {
                 uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
-                if (t0 < len) {   // (lanes whose window has ended fetch nothing: see lg_dtrefine_kernel)
+                if (t0 < len) {   // lanes whose window has ended fetch nothing: the rows are per lane (64 cache lines per wave
+                                  // instruction), and a few columns with long windows would make all 64 lanes fetch lines for them
 #pragma unroll
                     for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
                 }
@@ -1159,202 +1155,6 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
     if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
 }
 
-// ---- the refinement ladder: anchors every 32 rows (lg_dtanchor_kernel<1, 32>), then the rows half-way between two solved rows,
-// level by level (S = 16, 8, 4, 2, 1): the row y = ya + S between the solved rows ya and ya + 2S only looks at the candidate
-// rows between their minimisers.  ~10 evaluations per pixel instead of ~90 for the one-level search at the benchmark's leaf size
-// (the anchors 2d / 32, every level a window that halves with its spacing) -- at the price of one launch per level, which only
-// large batches can afford.  Wave = one target row x 64 columns, every lane its own window (per-lane rows, see lg_dtband_kernel).
-template <int S>
-__global__ __launch_bounds__(256) void lg_dtrefine_kernel(const unsigned long long* __restrict__ bits,
-                                                          const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
-                                                          float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
-                                                          int W, int WW, int wc, int G, int B) {
-    int frame, j;
-    if (!lg_frame_of_block(G, B, &frame, &j)) return;
-    const LgWin w = wins[frame];
-    if (!w.search_in) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wxe = min(W, w.wx0 + w.nw * wc);
-    const int ntx = (wxe - w.wx0 + 63) >> 6;
-    const int ntg = (w.wy1 - w.wy0 - S + 2 * S - 1) / (2 * S);        // target rows wy0 + S + 2 S m < wy1
-    const int nty = (max(ntg, 0) + 3) >> 2;                           // four target rows (waves) per workgroup tile
-    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);     // candidate rows
-    const unsigned long long* fb = bits + (size_t)frame * H * WW;
-    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
-    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;
-    float* dout = dist_out + (size_t)frame * H * W;
-    uint32_t mx = 0;
-    const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
-    for (int tile = j; tile < ntile; tile += G) {
-        const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
-        const int wi = (w.wx0 >> 6) + txi;
-        const int x = 64 * wi + lane, y = w.wy0 + S + 2 * S * (4 * tyi + wave);
-        if (y >= w.wy1) continue;   // (wave-uniform)
-        const bool xin = x < W;
-        const unsigned xc = (unsigned)min(x, W - 1);
-        const unsigned long long rb = lg_readlane_u64(fb[(unsigned)(y * WW + wi)], 0);
-        const bool on = xin && ((rb >> lane) & 1ull);
-        uint32_t best = on ? 0xFFFFFFFFu : 0u;
-        int arow = y;
-        if (rb) {
-            const int ya = y - S, yb = y + S;
-            const int a1 = argb[(unsigned)(ya * W) + xc];
-            const int a2 = yb <= w.by1 ? (int)argb[(unsigned)(min(yb, H - 1) * W) + xc] : hi;
-            const int first = max(min(a1, a2), lo);
-            const int len = on ? min(max(a1, a2), hi) - first + 1 : 0;
-            const int maxlen = lg_wave_max_i32(len);
-            for (int t0 = 0; t0 < maxlen; t0 += 4) {
-                // only lanes whose window reaches this group of four rows load at all: the rows are per lane (64 cache lines per
-                // wave instruction), and where a few columns cross the leaf's medial axis their long windows would otherwise make
-                // all 64 lanes fetch lines for a hundred rows -- the vector memory path, not the arithmetic, was the bound then
-                uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
-                if (t0 < len) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool act = t0 + q < len;
-                    if (__any(act && (hh4[q] << 16) < best)) {   // N(h, .) >= a * h
-                        const int yc = first + t0 + q;
-                        const int dy = y - yc;
-                        const uint32_t v = act ? lg_norm5_h(lg_h4(hh4[q]), (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
-                        arow = v < best ? yc : arow;
-                        best = min(best, v);
-                    }
-                }
-            }
-        }
-        mx = max(mx, best);
-        if (xin) {
-            dout[(unsigned)(y * W) + xc] = (float)best * (1.0f / 65536.0f);
-            if (S > 1) argb[(unsigned)(y * W) + xc] = (uint16_t)arow;
-        }
-    }
-    mx = lg_wave_max_u32(mx);
-    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
-}
-
-// ---- the ladder in ONE kernel, a 64-column strip of the window per workgroup, everything in LDS.  The ladder's five launches were
-// latency bound: every lane walks its window through dependent loads of per-lane rows, four rows per round trip to L2, and the few
-// lanes that cross the leaf's medial axis keep their wave for 25 trips at every level.  A strip's run distances (rows x 64
-// columns x 2 B) and minimising rows fit the 160 KB of LDS for windows of up to LG_STRIP_ROWS rows: staged once (coalesced), the
-// walks become LDS reads (same row for the whole wave in the anchor search: conflict-free; per-lane rows in the levels: at most
-// two lanes per bank), sixteen waves share the target rows of a level, barriers instead of launches.
-__global__ __launch_bounds__(1024) void lg_dtstrip_kernel(const unsigned long long* __restrict__ bits,
-                                                          const LgWin* __restrict__ wins, const uint32_t* __restrict__ tmp,
-                                                          float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H,
-                                                          int W, int WW, int wc, int G, int B) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    int frame, j;
-    if (!lg_frame_of_block(G, B, &frame, &j)) return;
-    const LgWin w = wins[frame];
-    if (!w.search_in) return;
-    const int wxe = min(W, w.wx0 + w.nw * wc);
-    const int ntx = (wxe - w.wx0 + 63) >> 6;
-    if (j >= ntx) return;
-    const int WR = w.wy1 - w.wy0;                                     // window rows (<= LG_STRIP_ROWS: lg_bbox_kernel)
-    uint16_t* const s_h = reinterpret_cast<uint16_t*>(s_raw);         // [WR + 2][64]: rows wy0 - 1 .. wy1 of the run distances
-    uint16_t* const s_arg = s_h + (size_t)(LG_STRIP_ROWS + 2) * 64;   // [WR][64]: a minimising row per solved pixel
-    unsigned long long* const s_bits = reinterpret_cast<unsigned long long*>(s_arg + (size_t)LG_STRIP_ROWS * 64);   // [WR]
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int NWV = 16;
-    const int wi = (w.wx0 >> 6) + j;
-    const int x = 64 * wi + lane;
-    const bool xin = x < W;
-    const unsigned xc = (unsigned)min(x, W - 1);
-    const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);     // candidate rows, inside [wy0 - 1, wy1]
-    const int hb = w.wy0 - 1;                                         // s_h row index = image row - hb
-    const unsigned long long* fb = bits + (size_t)frame * H * WW;
-    const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
-    float* dout = dist_out + (size_t)frame * H * W;
-    if (wi < (w.bx0 >> 6) || wi > (w.bx1 >> 6)) {                     // no leaf pixel in these columns: d_in = 0 (workgroup-uniform)
-        for (int y = w.wy0 + wave; y < w.wy1; y += NWV)
-            if (xin) dout[(unsigned)(y * W) + xc] = 0.0f;
-        return;
-    }
-    for (int y = lo + wave; y <= hi; y += NWV) s_h[(y - hb) * 64 + lane] = hd[(unsigned)(y * W) + xc];
-    for (int r = t; r < WR; r += 1024) s_bits[r] = fb[(unsigned)((w.wy0 + r) * WW + wi)];
-    __syncthreads();
-    uint32_t mx = 0;
-    // ---- anchors: rows wy0 + 32 m, every candidate row in reach, outwards from the row itself
-    for (int y = w.wy0 + 32 * wave; y < w.wy1; y += 32 * NWV) {
-        const unsigned long long rb = s_bits[y - w.wy0];
-        const bool on = xin && ((rb >> lane) & 1ull);
-        uint32_t best = on ? 0xFFFFFFFFu : 0u;
-        int arow = y;
-        if (rb) {
-            for (int k0 = 0;; k0 += 4) {
-                const int yu0 = y - k0, yd0 = y + 1 + k0;
-                if (yu0 < lo && yd0 > hi) break;
-                if (!__any((uint32_t)k0 * LG_A5 < best)) break;
-                uint32_t hu[4], hv[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    hu[q] = s_h[(min(max(yu0 - q, lo), hi) - hb) * 64 + lane];
-                    hv[q] = s_h[(max(min(yd0 + q, hi), lo) - hb) * 64 + lane];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int yu = yu0 - q, yd = yd0 + q;
-                    if (yu >= lo && yu <= hi && __any((hu[q] << 16) < best)) {
-                        const uint32_t v = lg_norm5_h(lg_h4(hu[q]), (uint32_t)(y - yu));
-                        arow = v < best ? yu : arow;
-                        best = min(best, v);
-                    }
-                    if (yd >= lo && yd <= hi && __any((hv[q] << 16) < best)) {
-                        const uint32_t v = lg_norm5_h(lg_h4(hv[q]), (uint32_t)(yd - y));
-                        arow = v < best ? yd : arow;
-                        best = min(best, v);
-                    }
-                }
-            }
-        }
-        mx = max(mx, best);
-        s_arg[(y - w.wy0) * 64 + lane] = (uint16_t)arow;
-        if (xin) dout[(unsigned)(y * W) + xc] = (float)best * (1.0f / 65536.0f);
-    }
-    __syncthreads();
-    // ---- levels: the row half-way between two solved rows from the candidate rows between their minimisers
-    for (int S = 16; S >= 1; S >>= 1) {
-        for (int y = w.wy0 + S + 2 * S * wave; y < w.wy1; y += 2 * S * NWV) {
-            const unsigned long long rb = s_bits[y - w.wy0];
-            const bool on = xin && ((rb >> lane) & 1ull);
-            uint32_t best = on ? 0xFFFFFFFFu : 0u;
-            int arow = y;
-            if (rb) {
-                const int a1 = s_arg[(y - S - w.wy0) * 64 + lane];
-                const int a2 = y + S <= w.by1 ? (int)s_arg[(y + S - w.wy0) * 64 + lane] : hi;
-                const int first = max(min(a1, a2), lo);
-                const int len = on ? min(max(a1, a2), hi) - first + 1 : 0;
-                const int maxlen = lg_wave_max_i32(len);
-                for (int t0 = 0; t0 < maxlen; t0 += 4) {
-                    uint32_t hh4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) hh4[q] = s_h[(min(first + t0 + q, hi) - hb) * 64 + lane];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const bool act = t0 + q < len;
-                        if (__any(act && (hh4[q] << 16) < best)) {
-                            const int yc = first + t0 + q;
-                            const int dy = y - yc;
-                            const uint32_t v = act ? lg_norm5_h(lg_h4(hh4[q]), (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
-                            arow = v < best ? yc : arow;
-                            best = min(best, v);
-                        }
-                    }
-                }
-            }
-            mx = max(mx, best);
-            if (S > 1) s_arg[(y - w.wy0) * 64 + lane] = (uint16_t)arow;
-            if (xin) dout[(unsigned)(y * W) + xc] = (float)best * (1.0f / 65536.0f);
-        }
-        __syncthreads();
-    }
-    mx = lg_wave_max_u32(mx);
-    if (lane == 0 && mx) atomicMax(&maxfix[frame * 2 + 0], mx);
-}
-
 static int lg_search_groups(int B, int per_batch, int lo, int hi) {
     const int bpad = 8 * ((B + 7) / 8);
     return std::max(lo, std::min(hi, per_batch / bpad));
@@ -1365,7 +1165,10 @@ void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* 
 }
 // algo 1: the one-level search of every row (one launch: small batches, where the launches' latency counts and the device is
 // not full); algo 2: anchor rows (phase 0), then the rows between them (phase 1); 3 / 4: the same with four / one anchor rows
-// per lane whatever the batch (tests).  Returns 0 when the phase has nothing to launch.
+// per lane whatever the batch (tests).  Returns 0 when the phase has nothing to launch.  (A refinement ladder -- anchors every
+// 32 rows, then the rows half-way between solved rows, level by level -- was built in two forms, six launches and one kernel
+// per 64-column strip with everything in LDS: exact, ten times fewer evaluations, and slower than every other form, because
+// a wave's long loops run for the few lanes that cross the leaf's medial axis: profiles/NOTES_r04.md.)
 int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
                        const LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
     static const int g_env = getenv("LG_DT_SEARCH_G") ? atoi(getenv("LG_DT_SEARCH_G")) : 0;
@@ -1375,33 +1178,6 @@ int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint
         if (phase) return 0;
         const int G = g_env > 0 ? g_env : lg_search_groups(B, 8192, 8, 256);
         hipLaunchKernelGGL(lg_dtsearch_kernel, dim3(nb8 * G), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, G, B);
-        return 1;
-    }
-    if (algo == 6) {   // the ladder inside one kernel, a 64-column strip of the window per workgroup
-        if (phase) return 0;
-        static const bool attr_ok = [] {
-            return hipFuncSetAttribute((const void*)lg_dtstrip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LG_STRIP_LDS) == hipSuccess;
-        }();
-        if (!attr_ok) return -1;
-        const int ns = std::min(64, (W + 63) / 64);   // workgroups per frame: one per 64-column strip a window can have
-        hipLaunchKernelGGL(lg_dtstrip_kernel, dim3(nb8 * ns), dim3(1024), LG_STRIP_LDS, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, ns, B);
-        return 1;
-    }
-    if (algo == 5) {   // the ladder: anchors every 32 rows, then levels 16, 8, 4, 2, 1
-        const int tiles32 = ((W + 63) / 64) * ((H + 127) / 128);
-        if (phase == 0) {
-            const int Ga = g_env > 0 ? g_env : std::min(tiles32, lg_search_groups(B, 16384, 8, 512));
-            hipLaunchKernelGGL((lg_dtanchor_kernel<1, 32>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
-            return 1;
-        }
-#define LG_REFINE(S_)                                                                                                          \
-    {                                                                                                                          \
-        const int tl = ((W + 63) / 64) * ((H + 8 * (S_) - 1) / (8 * (S_)));                                                    \
-        const int Gr = g_env > 0 ? g_env : std::min(tl, lg_search_groups(B, 32768, 8, 512));                                   \
-        hipLaunchKernelGGL(lg_dtrefine_kernel<S_>, dim3(nb8 * Gr), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Gr, B); \
-    }
-        LG_REFINE(16) LG_REFINE(8) LG_REFINE(4) LG_REFINE(2) LG_REFINE(1)
-#undef LG_REFINE
         return 1;
     }
     if (phase == 0) {

@@ -120,8 +120,9 @@ def test_anchor_and_band_search_with_arbitrary_minimisers():
 
 
 def test_refinement_ladder_with_arbitrary_minimisers():
-    """lg_dtanchor_kernel<1, 32> + lg_dtrefine_kernel<16 .. 1>: anchors every 32 rows, then the row half-way between two solved
-    rows from the candidate rows between their minimisers, level by level -- any minimiser at every level."""
+    """Identity 3 applied recursively: anchors every 32 rows, then the row half-way between two solved rows from the candidate
+    rows between their minimisers, level by level -- any minimiser at every level.  (The device forms built on it in round 4 were
+    exact and slower than anchors + bands, and were removed: profiles/NOTES_r04.md.)"""
     rng = np.random.default_rng(11)
     for mask in _cases(60, 2):
         H, W = mask.shape

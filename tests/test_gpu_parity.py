@@ -134,8 +134,7 @@ def _window_case(rng, H, W, kind):
 # search); the library picks per frame and batch size.  Every form must give the oracle's integers: the options are read when a
 # handle is created, so each form gets a selector of its own.
 DT_FORMS = {"auto": {}, "sweeps": {"LG_DT_SEARCH": "0"}, "search1": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "1"},
-            "search2_np4": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "3"}, "search2_np1": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "4"},
-            "ladder": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "5"}, "strip": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "6"}}
+            "search2_np4": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "3"}, "search2_np1": {"LG_DT_SEARCH": "1", "LG_DT_SEARCH_ALGO": "4"}}
 
 
 @pytest.fixture(scope="module")
@@ -183,7 +182,7 @@ def test_windowed_sweeps_are_exact(dt_sels, form):
     assert n_windowed >= 20   # the windowed path was actually exercised
 
 
-@pytest.mark.parametrize("form", ["search1", "search2_np4", "search2_np1", "ladder", "strip"])
+@pytest.mark.parametrize("form", ["search1", "search2_np4", "search2_np1"])
 def test_row_search_on_hard_masks(dt_sels, form):
     """Masks the row search has to get right beyond the window cases: a frame with a single zero pixel, full-width bands (rows
     without any zero pixel), leaves wider than 64 words' worth of columns is covered at 4K; thin diagonal strips (every
