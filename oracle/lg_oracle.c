@@ -527,10 +527,23 @@ int lg_greedy_nms(const int64_t* order, int64_t n, int H, int W, int top_k, int 
  * exact-EDT semantics can move the consumed arg-max (tests/test_oracle_fmm.py).  PARITY UNPINNED.
  */
 typedef struct { double v; int idx; } lg_hn;
+/* Tie order of the heap: 0 = whatever this heap's sift rules give (the default), 1 / 2 = equal values leave in increasing /
+ * decreasing flat-index order.  scikit-fmm's own heap has its own, different, rules; the knob exists to MEASURE what the tie
+ * order alone does to the field (tests/test_oracle_fmm.py): along straight edges a cell and its second neighbour tie, and
+ * which of them is frozen first decides between the first- and the second-order difference. */
+static int lg_fmm_tie = 0;
+static int lg_hn_le(const lg_hn* a, const lg_hn* b) {      /* a may stay above b */
+    if (a->v != b->v || lg_fmm_tie == 0) return a->v <= b->v;
+    return lg_fmm_tie == 1 ? a->idx <= b->idx : a->idx >= b->idx;
+}
+static int lg_hn_lt(const lg_hn* a, const lg_hn* b) {      /* a must move above b */
+    if (a->v != b->v || lg_fmm_tie == 0) return a->v < b->v;
+    return lg_fmm_tie == 1 ? a->idx < b->idx : a->idx > b->idx;
+}
 static void lg_heap_up(lg_hn* h, int* pos, int i) {
     while (i > 0) {
         int p = (i - 1) / 2;
-        if (h[p].v <= h[i].v) break;
+        if (lg_hn_le(&h[p], &h[i])) break;
         lg_hn t = h[p]; h[p] = h[i]; h[i] = t;
         pos[h[p].idx] = p; pos[h[i].idx] = i;
         i = p;
@@ -539,8 +552,8 @@ static void lg_heap_up(lg_hn* h, int* pos, int i) {
 static void lg_heap_down(lg_hn* h, int* pos, int n, int i) {
     for (;;) {
         int l = 2 * i + 1, r = l + 1, m = i;
-        if (l < n && h[l].v < h[m].v) m = l;
-        if (r < n && h[r].v < h[m].v) m = r;
+        if (l < n && lg_hn_lt(&h[l], &h[m])) m = l;
+        if (r < n && lg_hn_lt(&h[r], &h[m])) m = r;
         if (m == i) break;
         lg_hn t = h[m]; h[m] = h[i]; h[i] = t;
         pos[h[m].idx] = m; pos[h[i].idx] = i;
@@ -624,4 +637,9 @@ void lg_fmm_distance(const uint8_t* leaf, int H, int W, double* dist) {
     }
     for (i = 0; i < n; i++) if (dist[i] >= 1e299) dist[i] = 0.0;  /* no leaf at all */
     free(frozen); free(pos); free(heap);
+}
+void lg_fmm_distance_tie(const uint8_t* leaf, int H, int W, double* dist, int tie) {
+    lg_fmm_tie = tie;
+    lg_fmm_distance(leaf, H, W, dist);
+    lg_fmm_tie = 0;
 }

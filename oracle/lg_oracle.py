@@ -68,6 +68,8 @@ def _lib():
         L.lg_greedy_nms.restype = ctypes.c_int
         L.lg_fmm_distance.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         L.lg_fmm_distance.restype = None
+        L.lg_fmm_distance_tie.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        L.lg_fmm_distance_tie.restype = None
         _LIB = L
     return _LIB
 
@@ -668,12 +670,13 @@ def clutter_extrema(labels, method="edt"):
     return mn, mx
 
 
-def fmm_distance(leaf_bool):
+def fmm_distance(leaf_bool, tie=0):
     """Restated second-order fast marching (what skfmm.distance does at leaf_scorer.py:69); see lg_oracle.c.
-    Only used to quantify the EDT-vs-FMM deviation of the consumed arg-max.  PARITY UNPINNED."""
+    Only used to quantify the EDT-vs-FMM deviation of the consumed arg-max.  tie: order in which equal heap keys leave
+    (0 = this heap's own, 1 / 2 = increasing / decreasing flat index) -- a measuring knob.  PARITY UNPINNED."""
     a, p = _u8(np.asarray(leaf_bool).astype(np.uint8))
     out = np.empty(a.shape, np.float64)
-    _lib().lg_fmm_distance(p, a.shape[0], a.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    _lib().lg_fmm_distance_tie(p, a.shape[0], a.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(tie))
     return out
 
 
