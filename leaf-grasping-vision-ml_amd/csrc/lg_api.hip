@@ -48,6 +48,7 @@ struct lg_ctx {
     uint32_t* tmp = nullptr;
     unsigned long long *bits = nullptr, *stem = nullptr, *tilekeys = nullptr;
     uint32_t* maxfix = nullptr;
+    LgDtBatch* dt_batch = nullptr;   // search-or-sweeps sums of a batch (lg_bbox_kernel)
     LgWin* win = nullptr;           // [B] sweep windows (lg_bbox_kernel)
     LgFrameParams* fp_dev = nullptr;
     LgFrameParams* fp_host = nullptr;        // pinned
@@ -176,13 +177,13 @@ hipError_t dev_alloc(T** p, size_t n) {
 
 void free_ws(lg_ctx* h) {
     auto F = [](void* p) { if (p) hipFree(p); };
-    F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->win); F(h->fp_dev);
+    F(h->tmp); F(h->bits); F(h->stem); F(h->tilekeys); F(h->maxfix); F(h->dt_batch); F(h->win); F(h->fp_dev);
     for (int i = 0; i < LG_NUM_MAPS; i++) { F(h->ws_maps_base[i]); h->ws_maps_base[i] = h->ws_maps[i] = nullptr; }
     F(h->ws_valid); F(h->cand_xy); F(h->cand_n); F(h->cand_info); F(h->patches); F(h->logits);
     auto HF = [](void* p) { if (p) hipHostFree(p); };
     HF(h->fp_host); HF(h->bits_host); HF(h->win_host); HF(h->res_host);
     F(h->res_dev);
-    h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->win = nullptr; h->fp_dev = nullptr;
+    h->tmp = nullptr; h->bits = h->stem = h->tilekeys = nullptr; h->maxfix = nullptr; h->dt_batch = nullptr; h->win = nullptr; h->fp_dev = nullptr;
     h->ws_valid = nullptr; h->cand_xy = h->cand_n = nullptr; h->cand_info = h->patches = h->logits = nullptr;
     h->fp_host = nullptr; h->bits_host = nullptr; h->win_host = nullptr; h->bits_host_dev = nullptr; h->res_dev = h->res_host = nullptr;
     h->capB = h->capH = h->capW = h->capK = 0;
@@ -202,6 +203,8 @@ int ensure_ws(lg_ctx* h, int B, int H, int W, int K) {
     LG_HIP(h, dev_alloc(&h->stem, words));
     LG_HIP(h, dev_alloc(&h->tilekeys, (size_t)nB * tiles));
     LG_HIP(h, dev_alloc(&h->maxfix, (size_t)nB * 2));
+    LG_HIP(h, dev_alloc(&h->dt_batch, (size_t)1));
+    LG_HIP(h, hipMemset(h->dt_batch, 0, sizeof(LgDtBatch)));
     LG_HIP(h, dev_alloc(&h->win, (size_t)nB));
     LG_HIP(h, dev_alloc(&h->fp_dev, (size_t)nB));
     LG_HIP(h, hipHostMalloc((void**)&h->fp_host, sizeof(LgFrameParams) * nB));
@@ -502,7 +505,7 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     {
         ProfScope ps(h, "bbox", s);
-        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, h->opt_dt_search, s);
+        lg_launch_bbox(h->bits + off * words, h->win + off, n, pl.H, pl.W, pl.WW, h->opt_dt_search, h->dt_batch, s);
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
@@ -865,7 +868,7 @@ int lg_leaf_orientation(lg_handle h, const uint8_t* mask, int H, int W, float* o
     lg_launch_pack_bits(mask, h->bits, 1, H, W, WW, s);
     double o[5];
     if (h->orient) {   // the device analysis; a mask with more runs than its scratch holds falls through to the host code
-        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, 0, s);
+        lg_launch_bbox(h->bits, h->win, 1, H, W, WW, 0, nullptr, s);
         lg_launch_orient(h->orient, h->bits, h->win, h->fp_dev, 0, 1, H, W, WW, s);
         LG_HIP(h, hipMemcpyAsync(h->orient->h_out, h->orient->out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
         LG_HIP(h, hipMemcpyAsync(h->orient->h_status, h->orient->status, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -15,10 +15,12 @@
 #define LG_INF 0x3FFFFFFFu    // "no path yet" inside the DT sweeps (never wins against a real distance)
 #define LG_NOSRC 0x20000000u  // values >= this after the backward sweep mean: image has no source pixel
 #define LG_HCAP 16383u        // run distance of a row without any zero pixel in the image (row search; W <= 8192)
-// lg_bbox_kernel, search_mode 2: a frame's d_in comes from the row search while B * area^1.5 <= this * (rows of its bounding box)
+// lg_bbox_kernel, search_mode 2: a batch's d_in comes from the row search while sum over its frames of area^1.5 <= this *
+// (rows of its tallest bounding box)
 #ifndef LG_SEARCH_BUDGET
-#define LG_SEARCH_BUDGET 1.7e7f
+#define LG_SEARCH_BUDGET 2.0e7f
 #endif
+struct LgDtBatch { unsigned long long cost; unsigned rows, done; };   // the sums behind that decision (device; lg_bbox_kernel resets them)
 
 
 #define LG_MAX_GAUSS 15   // largest smoothing kernel lg_smooth_depth takes (the fused plane kernel: 1, 3, 5, 7)
@@ -104,7 +106,8 @@ void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* ste
 int lg_dt_geometry(int W, int* waves);
 // search_mode: 0 = d_in by the two sweeps for every frame, 1 = by the row search wherever it applies (a non-empty mask with
 // at least one zero pixel), 2 = the row search when the batch's estimated search work stays below the sweeps' latency
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s);
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, LgDtBatch* batch,
+                    hipStream_t s);
 // d_in without the row-sequential sweeps (frames with LgWin::search_in): horizontal run distances of the bounding-box rows into
 // `tmp` (the d_in half of the sweep workspace, as uint16), then the bounded search over rows, which writes distance_map inside
 // the window and the maximum into maxfix[b][0]

@@ -270,9 +270,18 @@ __device__ __forceinline__ uint32_t lg_norm5(int dx, int dy) {   // closed-form 
 // One workgroup per frame over the bit rows: bounding box of the set bits -> LgWin (see lg_internal.h).  1024 threads, four per
 // row (words q, q + 4, ...: the four read 32 adjacent bytes): a thread's loads are a dependent chain, and with one thread per
 // row and 256 threads the kernel took 44 us for ONE frame -- 6 % of a single-frame call.
+//
+// Search or sweeps is decided for the BATCH (search_mode 2): the search's time grows like the sum over the frames of area^1.5
+// (pixels x their depth), the sweeps' like the rows of the tallest window whatever the batch (one workgroup per frame, all at
+// once) -- and a batch of which one half is searched while the other half is swept takes as long as both together (measured:
+// 1.1 ms per 256 benchmark frames against 0.7 either way; the two forms do not run beside each other as their streams suggest).
+// Every workgroup adds its frame to the batch's sums; the last one to finish compares them and, if the sweeps win, clears
+// the flags of all frames (and resets the sums for the next launch).
 __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long* __restrict__ bits, LgWin* __restrict__ wins,
-                                                       int H, int W, int WW, int wc, int nw_max, int search_mode, float search_limit) {
+                                                       int H, int W, int WW, int wc, int nw_max, int search_mode, float search_budget,
+                                                       LgDtBatch* __restrict__ bt) {
     __shared__ int s_b[5];
+    __shared__ int s_last;
     const int frame = blockIdx.x, t = threadIdx.x;
     if (t == 0) { s_b[0] = INT_MAX; s_b[1] = -1; s_b[2] = INT_MAX; s_b[3] = -1; s_b[4] = 0; }
     __syncthreads();
@@ -310,9 +319,12 @@ __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long*
             // d_in by the row search (lg_dtsearch_kernel) needs a zero pixel in the image (a frame without one has OpenCV's
             // border-initialised result, which only the sweeps produce); its work grows like area^1.5 (pixels x their depth)
             // while the sweeps' time is set by the window's rows: `search_limit` is where the two meet for this batch.
-            const float a = (float)w.area;
-            w.search_in = (search_mode != 0 && (long long)w.area < (long long)H * W &&
-                           (search_mode == 1 || a * __builtin_sqrtf(a) <= search_limit * (float)(w.by1 - w.by0 + 1))) ? 1 : 0;
+            w.search_in = (search_mode != 0 && (long long)w.area < (long long)H * W) ? 1 : 0;
+            if (search_mode == 2 && w.search_in) {
+                const float a = (float)w.area;
+                atomicAdd(&bt->cost, (unsigned long long)(a * __builtin_sqrtf(a)));
+                atomicMax(&bt->rows, (unsigned)(w.by1 - w.by0 + 1));
+            }
             w.wx0 = (w.bx0 / LG_TW) * LG_TW;
             w.nw = (w.bx1 + 1 - w.wx0 + wc - 1) / wc;
             w.wy0 = (w.by0 / LG_TH) * LG_TH;
@@ -331,18 +343,33 @@ __global__ __launch_bounds__(1024) void lg_bbox_kernel(const unsigned long long*
         }
         w.pad_[0] = 0;
         wins[frame] = w;
+        s_last = 0;
+        if (search_mode == 2) {
+            __threadfence();
+            s_last = atomicAdd(&bt->done, 1u) == gridDim.x - 1 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (s_last) {   // (one workgroup of the launch; every other one has published its frame and its sums)
+        __threadfence();
+        const unsigned long long cost = atomicAdd(&bt->cost, 0ull);
+        const unsigned rows = atomicMax(&bt->rows, 0u);
+        if ((float)cost > search_budget * (float)rows)
+            for (int f = t; f < (int)gridDim.x; f += 1024) wins[f].search_in = 0;
+        if (t == 0) { bt->cost = 0; bt->rows = 0; bt->done = 0; }
     }
 }
 
-void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, hipStream_t s) {
+void lg_launch_bbox(const unsigned long long* bits, LgWin* win, int B, int H, int W, int WW, int search_mode, LgDtBatch* batch,
+                    hipStream_t s) {
     int nw = 0;
     const int wc = lg_dt_geometry(W, &nw);
-    // mode 2: the search's time grows like (frames in the batch) x area^1.5 -- 0.8 ms for 256 benchmark leaves of 93 k pixels --,
-    // the sweeps take ~1.65 us per row of the window whatever the batch (one workgroup per frame): a frame is searched while
-    // B * area^1.5 <= LG_SEARCH_BUDGET * rows.  LG_DT_SEARCH_LIMIT=<x> replaces LG_SEARCH_BUDGET / B (experiments).
-    static const float env_limit = getenv("LG_DT_SEARCH_LIMIT") ? (float)atof(getenv("LG_DT_SEARCH_LIMIT")) : 0.0f;
-    const float limit = env_limit > 0.0f ? env_limit : LG_SEARCH_BUDGET / (float)(B > 0 ? B : 1);
-    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(1024), 0, s, bits, win, H, W, WW, wc, nw, search_mode, limit);
+    // mode 2: search while sum over the frames of area^1.5 <= LG_SEARCH_BUDGET * rows of the tallest window: 0.69 ms for 256
+    // benchmark leaves of 100 k pixels in either form (anchors + bands; sweeps: ~1.6 us per row).  LG_DT_SEARCH_BUDGET=<x>
+    // replaces the constant (experiments).
+    static const float env_budget = getenv("LG_DT_SEARCH_BUDGET") ? (float)atof(getenv("LG_DT_SEARCH_BUDGET")) : 0.0f;
+    hipLaunchKernelGGL(lg_bbox_kernel, dim3(B), dim3(1024), 0, s, bits, win, H, W, WW, wc, nw, search_mode,
+                       env_budget > 0.0f ? env_budget : LG_SEARCH_BUDGET, batch);
 }
 
 // ============================================================================ max d_out outside the sweep window
@@ -1068,7 +1095,25 @@ __device__ __forceinline__ int lg_wave_max_i32(int v) {
     return v;
 }
 
+// minimum over the wave in six DPP steps (quads, half rows, rows, then the two row broadcasts): every lane gets it
+__device__ __forceinline__ uint32_t lg_wave_min_u32(uint32_t v) {
+#define LG_DPP_MIN(CTRL, RM) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, RM, 0xf, false))
+    LG_DPP_MIN(0xB1, 0xf);    // quad_perm 1 0 3 2
+    LG_DPP_MIN(0x4E, 0xf);    // quad_perm 2 3 0 1
+    LG_DPP_MIN(0x141, 0xf);   // row_half_mirror
+    LG_DPP_MIN(0x140, 0xf);   // row_mirror
+    LG_DPP_MIN(0x142, 0xa);   // row_bcast15 into rows 1 and 3
+    LG_DPP_MIN(0x143, 0xc);   // row_bcast31 into rows 2 and 3
+#undef LG_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Workgroup tile = 64 columns x 32 rows, wave = the seven rows between the anchor rows ya and ya + 8, lane = column.
+// Windows longer than LG_BAND_LONG rows -- the columns where the band crosses the leaf's medial axis: the anchor above is
+// minimised from the leaf's upper edge, the anchor below from its lower edge, the window is the leaf's whole thickness -- are
+// not walked by their lane (the other 63 lanes of the wave would wait for ~thickness / 4 round trips) but by the whole wave:
+// lane t takes candidate row first + t of that column, seven wave minima fold the result.
+#define LG_BAND_LONG 16
 __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long* __restrict__ bits,
                                                         const LgWin* __restrict__ wins, const uint32_t* __restrict__ tmp,
                                                         float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H, int W,
@@ -1116,7 +1161,10 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
             const int a2 = yb <= w.by1 ? (int)argb[(unsigned)(min(yb, H - 1) * W) + xc] : hi;
             const bool mine = xin && ((anyb >> lane) & 1ull);
             const int first = max(min(a1, a2), lo);
-            const int len = mine ? min(max(a1, a2), hi) - first + 1 : 0;
+            const int len_all = mine ? min(max(a1, a2), hi) - first + 1 : 0;
+            unsigned long long lm = __ballot(len_all > LG_BAND_LONG);
+            if (__popcll(lm) > 24) lm = 0;   // (a band ALONG the medial axis: every lane is long, the per-lane walk keeps them all busy)
+            const int len = ((lm >> lane) & 1ull) ? 0 : len_all;
             const int maxlen = lg_wave_max_i32(len);
             for (int t0 = 0; t0 < maxlen; t0 += 4) {
                 uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
@@ -1141,6 +1189,31 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
                             best[r] = min(best[r], act ? v : 0xFFFFFFFFu);
                         }
                     }
+                }
+            }
+            while (lm) {   // the long windows, one column at a time, 64 candidate rows per step
+                const int L = __builtin_ctzll(lm);
+                lm &= lm - 1;
+                const int fL = __builtin_amdgcn_readlane(first, L), nL = __builtin_amdgcn_readlane(len_all, L);
+                const unsigned xL = (unsigned)__builtin_amdgcn_readlane((int)xc, L);
+                uint32_t b[7];
+#pragma unroll
+                for (int r = 0; r < 7; r++) b[r] = 0xFFFFFFFFu;
+                for (int t0 = 0; t0 < nL; t0 += 64) {
+                    const int yc = fL + t0 + lane;
+                    const bool act = t0 + lane < nL;
+                    const LgH4 hh = lg_h4(act ? (uint32_t)hd[(unsigned)(yc * W) + xL] : (uint32_t)LG_HCAP);
+#pragma unroll
+                    for (int r = 0; r < 7; r++) {
+                        const int dy = ya + 1 + r - yc;
+                        const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
+                        b[r] = min(b[r], act ? v : 0xFFFFFFFFu);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    const uint32_t m = lg_wave_min_u32(b[r]);
+                    best[r] = lane == L ? min(best[r], m) : best[r];   // (an off-leaf pixel of the column keeps its 0)
                 }
             }
         }
