@@ -568,11 +568,17 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
             lg_launch_hrun(h->bits + off * words, h->tmp + 2 * off * px, h->win + off, n, pl.H, pl.W, pl.WW, ss);
         }
         const int algo = dt_algo(h, n, pl.H, pl.W);
-        for (int phase = 0; phase < (algo == 1 ? 1 : 2); phase++) {
-            ProfScope ps(h, phase ? "dt_band" : "dt_search", ss);
-            if (lg_launch_dtsearch(phase, algo, h->bits + off * words, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
-                                   h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, pl.WW, ss) < 0)
-                return fail(h, LG_ERR_HIP, "distance transform: the search kernels could not be launched");
+        auto launch = [&](int phase) {
+            return lg_launch_dtsearch(phase, algo, h->bits + off * words, h->tmp + 2 * off * px, pl.maps[LG_MAP_DISTANCE] + off * px,
+                                      h->maxfix + 2 * (size_t)off, h->win + off, n, pl.H, pl.W, pl.WW, ss);
+        };
+        {
+            ProfScope ps(h, "dt_search", ss);   // the one-level search, or the anchor rows
+            launch(0);
+        }
+        if (algo != 1) {
+            ProfScope ps(h, "dt_band", ss);     // the rows between the anchors
+            for (int phase = 1; launch(phase) > 0; phase++) {}
         }
         if (ss != s) LG_HIP(h, hipEventRecord(h->ev_search, ss));
     }

@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void lg_dtsearch_kernel(const unsigned long lo
 // makes Hirata's / Meijster's lower-envelope scans work for chamfer metrics).  So if a1 minimises at row y1 and a2 at row
 // y2 > y1 (ANY minimisers), every row y1 < y < y2 has a minimiser in [min(a1, a2), max(a1, a2)].
 //   lg_dtanchor_kernel: rows y % 8 == 0 of the window by the bounded search, recording a minimising row per pixel;
-//   lg_dtband_kernel:   the seven rows between two anchor rows, candidates = the union over the wave's columns of
+//   lg_dtlevel_kernel:  the seven rows between two anchor rows, candidates = the union over the wave's columns of
 //                       [anchor above's row, anchor below's row] -- a dozen rows where the nearest edge stays on one side,
 //                       the leaf's whole thickness where the band crosses its medial axis (once per column).
 // ~5x fewer candidate evaluations than the one-level search at the benchmark's leaf size; same integers.
@@ -1108,62 +1108,70 @@ __device__ __forceinline__ uint32_t lg_wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Workgroup tile = 64 columns x 32 rows, wave = the seven rows between the anchor rows ya and ya + 8, lane = column.
-// Windows longer than LG_BAND_LONG rows -- the columns where the band crosses the leaf's medial axis: the anchor above is
-// minimised from the leaf's upper edge, the anchor below from its lower edge, the window is the leaf's whole thickness -- are
-// not walked by their lane (the other 63 lanes of the wave would wait for ~thickness / 4 round trips) but by the whole wave:
-// lane t takes candidate row first + t of that column, seven wave minima fold the result.
-#define LG_BAND_LONG 16
-__global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long* __restrict__ bits,
-                                                        const LgWin* __restrict__ wins, const uint32_t* __restrict__ tmp,
-                                                        float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H, int W,
-                                                        int WW, int wc, int G, int B) {
+// One level of the row search between solved rows.  A group = the NT target rows ya + ST (r + 1), r < NT, between the solved
+// rows ya and ya + GH (GH = ST (NT + 1)), whose minimising rows bound every target's candidates; wave = one group x 64 columns,
+// lane = column, workgroup = four consecutive groups.  <7, 1>: the seven rows between anchors eight rows apart (distances
+// only; ST > 1 also records the targets' minimising rows, for a further level -- measured slower, see lg_launch_dtsearch).
+// Windows longer than GH + 8 rows -- the columns where the group crosses the leaf's medial axis: the row above is minimised from
+// the leaf's upper edge, the row below from its lower edge, the window is the leaf's whole thickness -- are not walked by their
+// lane (the other 63 lanes of the wave would wait for ~thickness / 4 round trips) but by the whole wave: lane t takes candidate row first + t of that column, wave minima fold the result.
+template <int NT, int ST>
+__global__ __launch_bounds__(256) void lg_dtlevel_kernel(const unsigned long long* __restrict__ bits,
+                                                         const LgWin* __restrict__ wins, uint32_t* __restrict__ tmp,
+                                                         float* __restrict__ dist_out, uint32_t* __restrict__ maxfix, int H, int W,
+                                                         int WW, int wc, int G, int B) {
+    constexpr int GH = ST * (NT + 1), LONG = GH + 8;
+    constexpr bool ARG = ST > 1;   // the targets are solved rows of a later level
     int frame, j;
     if (!lg_frame_of_block(G, B, &frame, &j)) return;
     const LgWin w = wins[frame];
     if (!w.search_in) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wxe = min(W, w.wx0 + w.nw * wc);
-    const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + 31) >> 5;
+    const int ntx = (wxe - w.wx0 + 63) >> 6, nty = (w.wy1 - w.wy0 + 4 * GH - 1) / (4 * GH);
     const int lo = max(w.by0 - 1, 0), hi = min(w.by1 + 1, H - 1);   // candidate rows
     const unsigned long long* fb = bits + (size_t)frame * H * WW;
     const uint16_t* hd = reinterpret_cast<const uint16_t*>(tmp + (size_t)frame * 2 * H * W);
-    const uint16_t* argb = hd + (size_t)H * W;
+    uint16_t* argb = reinterpret_cast<uint16_t*>(tmp + (size_t)frame * 2 * H * W) + (size_t)H * W;
     float* dout = dist_out + (size_t)frame * H * W;
     uint32_t mx = 0;
     const int ntile = __builtin_amdgcn_readfirstlane(ntx * nty);
     for (int tile = j; tile < ntile; tile += G) {
         const int tyi = __builtin_amdgcn_readfirstlane(tile / ntx), txi = tile - tyi * ntx;
         const int wi = (w.wx0 >> 6) + txi;
-        const int x = 64 * wi + lane, ya = w.wy0 + 32 * tyi + 8 * wave;
-        if (ya + 1 >= w.wy1) continue;   // (wave-uniform)
+        const int x = 64 * wi + lane, ya = w.wy0 + 4 * GH * tyi + GH * wave;
+        if (ya + ST >= w.wy1) continue;   // (wave-uniform)
         const bool xin = x < W;
         const unsigned xc = (unsigned)min(x, W - 1);
-        unsigned long long rb[7], anyb = 0;
+        unsigned long long rb[NT], anyb = 0;
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            const int y = ya + 1 + r;
+        for (int r = 0; r < NT; r++) {
+            const int y = ya + ST * (r + 1);
             rb[r] = fb[(unsigned)(min(y, H - 1) * WW + wi)];
             rb[r] = y < w.wy1 ? lg_readlane_u64(rb[r], 0) : 0ull;
             anyb |= rb[r];
         }
-        uint32_t best[7];
+        uint32_t best[NT];
+        int arow[NT];
 #pragma unroll
-        for (int r = 0; r < 7; r++) best[r] = (xin && ((rb[r] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
+        for (int r = 0; r < NT; r++) {
+            best[r] = (xin && ((rb[r] >> lane) & 1ull)) ? 0xFFFFFFFFu : 0u;
+            arow[r] = ya + ST * (r + 1);   // an off-leaf pixel is its own nearest zero pixel
+        }
         if (anyb) {
-            // this lane's candidate rows: between the minimising rows of its two anchors (the anchor below the last leaf row
+            // this lane's candidate rows: between the minimising rows of the two solved rows (the row below the last leaf row
             // would be an off-leaf pixel minimised by itself: every row down to `hi` then).  Every lane walks ITS OWN rows
             // (row = first + t): along a tilted edge the windows of neighbouring columns are shifted against each other, and a
             // row shared by the whole wave would have to cover their union -- 64 columns x the edge's slope.  The loads are then
-            // per-lane rows (neighbouring lanes mostly hit the same or the next line; seven evaluations pay for each).
+            // per-lane rows (neighbouring lanes mostly hit the same or the next line; NT evaluations pay for each).
             const int a1 = argb[(unsigned)(ya * W) + xc];
-            const int yb = ya + 8;
+            const int yb = ya + GH;
             const int a2 = yb <= w.by1 ? (int)argb[(unsigned)(min(yb, H - 1) * W) + xc] : hi;
             const bool mine = xin && ((anyb >> lane) & 1ull);
             const int first = max(min(a1, a2), lo);
             const int len_all = mine ? min(max(a1, a2), hi) - first + 1 : 0;
-            unsigned long long lm = __ballot(len_all > LG_BAND_LONG);
-            if (__popcll(lm) > 24) lm = 0;   // (a band ALONG the medial axis: every lane is long, the per-lane walk keeps them all busy)
+            unsigned long long lm = __ballot(len_all > LONG);
+            if (__popcll(lm) > 24) lm = 0;   // (a group ALONG the medial axis: every lane is long, the per-lane walk keeps them all busy)
             const int len = ((lm >> lane) & 1ull) ? 0 : len_all;
             const int maxlen = lg_wave_max_i32(len);
             for (int t0 = 0; t0 < maxlen; t0 += 4) {
@@ -1178,15 +1186,16 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
                     const bool act = t0 + q < len;
                     uint32_t bq = best[0];
 #pragma unroll
-                    for (int r = 1; r < 7; r++) bq = max(bq, best[r]);
+                    for (int r = 1; r < NT; r++) bq = max(bq, best[r]);
                     if (__any(act && (hh4[q] << 16) < bq)) {   // N(h, .) >= a * h: a row that cannot improve any lane is skipped
                         const LgH4 hh = lg_h4(hh4[q]);
                         const int yc = first + t0 + q;
 #pragma unroll
-                        for (int r = 0; r < 7; r++) {
-                            const int dy = ya + 1 + r - yc;
-                            const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
-                            best[r] = min(best[r], act ? v : 0xFFFFFFFFu);
+                        for (int r = 0; r < NT; r++) {
+                            const int dy = ya + ST * (r + 1) - yc;
+                            const uint32_t v = act ? lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
+                            if (ARG) arow[r] = v < best[r] ? yc : arow[r];
+                            best[r] = min(best[r], v);
                         }
                     }
                 }
@@ -1196,32 +1205,41 @@ __global__ __launch_bounds__(256) void lg_dtband_kernel(const unsigned long long
                 lm &= lm - 1;
                 const int fL = __builtin_amdgcn_readlane(first, L), nL = __builtin_amdgcn_readlane(len_all, L);
                 const unsigned xL = (unsigned)__builtin_amdgcn_readlane((int)xc, L);
-                uint32_t b[7];
+                uint32_t b[NT];
+                int br[NT];
 #pragma unroll
-                for (int r = 0; r < 7; r++) b[r] = 0xFFFFFFFFu;
+                for (int r = 0; r < NT; r++) { b[r] = 0xFFFFFFFFu; br[r] = 0xFFFF; }
                 for (int t0 = 0; t0 < nL; t0 += 64) {
                     const int yc = fL + t0 + lane;
                     const bool act = t0 + lane < nL;
                     const LgH4 hh = lg_h4(act ? (uint32_t)hd[(unsigned)(yc * W) + xL] : (uint32_t)LG_HCAP);
 #pragma unroll
-                    for (int r = 0; r < 7; r++) {
-                        const int dy = ya + 1 + r - yc;
-                        const uint32_t v = lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy));
-                        b[r] = min(b[r], act ? v : 0xFFFFFFFFu);
+                    for (int r = 0; r < NT; r++) {
+                        const int dy = ya + ST * (r + 1) - yc;
+                        const uint32_t v = act ? lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
+                        if (ARG) br[r] = v < b[r] ? yc : br[r];
+                        b[r] = min(b[r], v);
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 7; r++) {
+                for (int r = 0; r < NT; r++) {
                     const uint32_t m = lg_wave_min_u32(b[r]);
+                    if (ARG) {   // a row that attains the minimum (any of them)
+                        const int mr = (int)lg_wave_min_u32(b[r] == m ? (uint32_t)br[r] : 0xFFFFu);
+                        arow[r] = (lane == L && m < best[r]) ? mr : arow[r];
+                    }
                     best[r] = lane == L ? min(best[r], m) : best[r];   // (an off-leaf pixel of the column keeps its 0)
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            const int y = ya + 1 + r;
+        for (int r = 0; r < NT; r++) {
+            const int y = ya + ST * (r + 1);
             mx = max(mx, best[r]);
-            if (xin && y < w.wy1) dout[(unsigned)(y * W) + xc] = (float)best[r] * (1.0f / 65536.0f);
+            if (xin && y < w.wy1) {
+                dout[(unsigned)(y * W) + xc] = (float)best[r] * (1.0f / 65536.0f);
+                if (ARG) argb[(unsigned)(y * W) + xc] = (uint16_t)arow[r];
+            }
         }
     }
     mx = lg_wave_max_u32(mx);
@@ -1237,34 +1255,40 @@ void lg_launch_hrun(const unsigned long long* bits, uint32_t* tmp, const LgWin* 
     hipLaunchKernelGGL(lg_hrun_kernel, dim3(8u * G * ((B + 7) / 8)), dim3(256), 0, s, bits, win, tmp, H, W, WW, G, B);
 }
 // algo 1: the one-level search of every row (one launch: small batches, where the launches' latency counts and the device is
-// not full); algo 2: anchor rows (phase 0), then the rows between them (phase 1); 3 / 4: the same with four / one anchor rows
-// per lane whatever the batch (tests).  Returns 0 when the phase has nothing to launch.  (A refinement ladder -- anchors every
-// 32 rows, then the rows half-way between solved rows, level by level -- was built in two forms, six launches and one kernel
-// per 64-column strip with everything in LDS: exact, ten times fewer evaluations, and slower than every other form, because
-// a wave's long loops run for the few lanes that cross the leaf's medial axis: profiles/NOTES_r04.md.)
+// not full); algo 2: anchor rows every 8 (phase 0), then the rows between them (phase 1); 3 / 4: the same with four / one anchor
+// rows per lane whatever the batch (tests).  Returns 0 when the algorithm has no such phase.  (Ladders -- anchors every 32 or 16
+// rows, then the rows half-way between solved rows, level by level -- were built three times: six launches of one target row per
+// wave, one kernel per 64-column strip with everything in LDS, and lg_dtlevel_kernel<1, 8> / <1, 4> / <3, 1> under anchors every
+// 16 rows.  All exact, up to ten times fewer evaluations, all slower: a level's wave pays its fixed cost -- bit rows, the two
+// solved rows' minimisers, window, stores: three dependent round trips -- for one or three rows of work instead of seven, and
+// the anchors' cost does not halve with their number.  profiles/NOTES_r04.md.)
 int lg_launch_dtsearch(int phase, int algo, const unsigned long long* bits, uint32_t* tmp, float* dist_out, uint32_t* maxfix,
                        const LgWin* win, int B, int H, int W, int WW, hipStream_t s) {
     static const int g_env = getenv("LG_DT_SEARCH_G") ? atoi(getenv("LG_DT_SEARCH_G")) : 0;
     const int wc = lg_dt_geometry(W, nullptr);
     const unsigned nb8 = 8u * (unsigned)((B + 7) / 8);
+    const int tx = (W + 63) / 64;
+#define LG_LAUNCH_SEARCH(K, G_) hipLaunchKernelGGL(K, dim3(nb8 * (G_)), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, G_, B)
     if (algo == 1) {
         if (phase) return 0;
         const int G = g_env > 0 ? g_env : lg_search_groups(B, 8192, 8, 256);
-        hipLaunchKernelGGL(lg_dtsearch_kernel, dim3(nb8 * G), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, G, B);
+        LG_LAUNCH_SEARCH(lg_dtsearch_kernel, G);
         return 1;
     }
     if (phase == 0) {
         const bool np4 = algo == 3 || (algo == 2 && B >= 128);   // (32 frames: 0.071 vs 0.100 ms with one / four anchors per lane)
         // workgroups per frame: the window's tiles (64 columns x 128 / 32 rows) when the grid allows -- leaf tiles cluster, and a
         // workgroup that walks several of them with a fixed stride gets several heavy ones or none
-        const int tiles = ((W + 63) / 64) * ((H + (np4 ? 127 : 31)) / (np4 ? 128 : 32));
-        const int Ga = g_env > 0 ? g_env : std::min(tiles, lg_search_groups(B, 16384, 8, 512));
-        if (np4) hipLaunchKernelGGL((lg_dtanchor_kernel<4, 8>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
-        else hipLaunchKernelGGL((lg_dtanchor_kernel<1, 8>), dim3(nb8 * Ga), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Ga, B);
+        const int trows = np4 ? 128 : 32;
+        const int Ga = g_env > 0 ? g_env : std::min(tx * ((H + trows - 1) / trows), lg_search_groups(B, 16384, 8, 512));
+        if (np4) LG_LAUNCH_SEARCH((lg_dtanchor_kernel<4, 8>), Ga);
+        else LG_LAUNCH_SEARCH((lg_dtanchor_kernel<1, 8>), Ga);
         return 1;
     }
-    const int Gb = g_env > 0 ? g_env : std::min(((W + 63) / 64) * ((H + 31) / 32), lg_search_groups(B, 32768, 8, 512));
-    hipLaunchKernelGGL(lg_dtband_kernel, dim3(nb8 * Gb), dim3(256), 0, s, bits, win, tmp, dist_out, maxfix, H, W, WW, wc, Gb, B);
+    if (phase > 1) return 0;
+    const int Gb = g_env > 0 ? g_env : std::min(tx * ((H + 31) / 32), lg_search_groups(B, 32768, 8, 512));
+    LG_LAUNCH_SEARCH((lg_dtlevel_kernel<7, 1>), Gb);
+#undef LG_LAUNCH_SEARCH
     return 1;
 }
 
