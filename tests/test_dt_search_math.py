@@ -1,5 +1,5 @@
 """The identities the device's sweep-free distance transform rests on (lg_hrun_kernel / lg_dtsearch_kernel / lg_dtanchor_kernel /
-lg_dtband_kernel, csrc/lg_kernels.hip), checked on the CPU against the oracle's two-pass chamfer transform
+lg_dtlevel_kernel, csrc/lg_kernels.hip), checked on the CPU against the oracle's two-pass chamfer transform
 (cv2.distanceTransform(mask, DIST_L2, 5), grasp_point_selector.py:266, :529):
   1. d(x, y) = min over rows y' of N(h[y'][x], |y - y'|) with h = distance to the row's nearest zero pixel and N the closed-form
      chamfer norm; rows outside [by0 - 1, by1 + 1] never matter;
