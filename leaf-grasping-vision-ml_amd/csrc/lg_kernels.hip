@@ -1108,6 +1108,12 @@ __device__ __forceinline__ uint32_t lg_wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ uint32_t lg_absdiff(int a, int b) {   // |a - b| in one instruction (hipcc emits add, sub, max)
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // One level of the row search between solved rows.  A group = the NT target rows ya + ST (r + 1), r < NT, between the solved
 // rows ya and ya + GH (GH = ST (NT + 1)), whose minimising rows bound every target's candidates; wave = one group x 64 columns,
 // lane = column, workgroup = four consecutive groups.  <7, 1>: the seven rows between anchors eight rows apart (distances
@@ -1175,25 +1181,26 @@ __global__ __launch_bounds__(256) void lg_dtlevel_kernel(const unsigned long lon
             const int len = ((lm >> lane) & 1ull) ? 0 : len_all;
             const int maxlen = lg_wave_max_i32(len);
             for (int t0 = 0; t0 < maxlen; t0 += 4) {
+                // a row past the lane's window counts as a row without a zero pixel (LG_HCAP: beats nothing, see lg_hrun_kernel)
                 uint32_t hh4[4] = {LG_HCAP, LG_HCAP, LG_HCAP, LG_HCAP};
                 if (t0 < len) {   // lanes whose window has ended fetch nothing: the rows are per lane (64 cache lines per wave
                                   // instruction), and a few columns with long windows would make all 64 lanes fetch lines for them
 #pragma unroll
                     for (int q = 0; q < 4; q++) hh4[q] = hd[(unsigned)(min(first + t0 + q, hi) * W) + xc];
+#pragma unroll
+                    for (int q = 1; q < 4; q++) hh4[q] = t0 + q < len ? hh4[q] : (uint32_t)LG_HCAP;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const bool act = t0 + q < len;
                     uint32_t bq = best[0];
 #pragma unroll
                     for (int r = 1; r < NT; r++) bq = max(bq, best[r]);
-                    if (__any(act && (hh4[q] << 16) < bq)) {   // N(h, .) >= a * h: a row that cannot improve any lane is skipped
+                    if (__any((hh4[q] << 16) < bq)) {   // N(h, .) >= a * h: a row that cannot improve any lane is skipped
                         const LgH4 hh = lg_h4(hh4[q]);
                         const int yc = first + t0 + q;
 #pragma unroll
                         for (int r = 0; r < NT; r++) {
-                            const int dy = ya + ST * (r + 1) - yc;
-                            const uint32_t v = act ? lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
+                            const uint32_t v = lg_norm5_h(hh, lg_absdiff(yc, ya + ST * (r + 1)));
                             if (ARG) arow[r] = v < best[r] ? yc : arow[r];
                             best[r] = min(best[r], v);
                         }
@@ -1215,8 +1222,7 @@ __global__ __launch_bounds__(256) void lg_dtlevel_kernel(const unsigned long lon
                     const LgH4 hh = lg_h4(act ? (uint32_t)hd[(unsigned)(yc * W) + xL] : (uint32_t)LG_HCAP);
 #pragma unroll
                     for (int r = 0; r < NT; r++) {
-                        const int dy = ya + ST * (r + 1) - yc;
-                        const uint32_t v = act ? lg_norm5_h(hh, (uint32_t)(dy < 0 ? -dy : dy)) : 0xFFFFFFFFu;
+                        const uint32_t v = lg_norm5_h(hh, lg_absdiff(yc, ya + ST * (r + 1)));
                         if (ARG) br[r] = v < b[r] ? yc : br[r];
                         b[r] = min(b[r], v);
                     }
