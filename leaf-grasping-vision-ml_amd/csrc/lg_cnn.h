@@ -36,6 +36,8 @@ struct LgCnn {
     size_t act_per[8] = {0};      //   last layer dense [coutp][wo*wo] for the head; one buffer per layer: halos stay zero
     float* in_halo = nullptr;     // haloed copy [capN][12][34][36] (9 feature planes + 3 zero planes) of dense input patches (lg_cnn_forward through the C-ABI)
     float* zeros = nullptr;       // 4096 zero floats
+    float* kpart = nullptr;       // lg_wino4_kernel: partial accumulators of items split along the input channels, one slot per workgroup
+    unsigned* kflag = nullptr;    //   and the counters of the parts that have arrived
     int wino_mask = 0x3f;         // bit L = layer L on Winograd (LG_CNN_DIRECT / LG_CNN_WINO_MASK at load time; bits 1..5: standard encoder only)
     int capN = 0;
 };

@@ -572,9 +572,10 @@ __device__ __forceinline__ void lg_lds_wait2(lg_f32x4& a, lg_f32x4& b) {
 //   Inside a chunk the fragment reads run two position groups ahead of the MFMAs that use them (3-deep register ring,
 //   hand-counted lgkmcnt waits); the work for the NEXT chunk is split by role between the two waves of every SIMD (see
 //   "roles" in the kernel): one transforms, the other issues the DMA transfers; ONE barrier per chunk.
-template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR>
+template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR, bool SPLIT>
 __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__ in, const float* __restrict__ U4,
-                                                       const float* __restrict__ bias, float* __restrict__ out, int N, int ntb) {
+                                                       const float* __restrict__ bias, float* __restrict__ out, int N, int ntb,
+                                                       float* __restrict__ kpart, unsigned* __restrict__ kflag) {
     constexpr int KC = 4;
     constexpr int TC = WI / 4, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per item
@@ -621,17 +622,37 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
     // so at any time they work on neighbouring positions.  Small U (fits L2 beside the inputs): channel block fastest, the NCB
     // readers of an input band run back to back.  Large U (layers 4-5: 4.7 / 9.4 MB against 4 MB of L2): channel block
     // slowest, every CU of the XCD streams the SAME 64-channel slice of U while the XCD's input bands stream past.
+    //
+    // The tail: llen items on gx workgroups are R full rounds and r left-over items.  Left over, they would cost a whole round
+    // on r of the gx workgroups (640 patches: 40 items of an 8 x 8 layer on 32 workgroups per XCD -- two rounds where 1.25 would
+    // do; one frame: 4 items, 28 workgroups idle).  Each left-over item is split over P workgroups along the INPUT CHANNELS
+    // (chunks [part * NC / P, (part + 1) * NC / P): the chunk pipeline is unchanged, it only starts and ends elsewhere);
+    // the first P - 1 parts publish their partial outputs through L2 (kpart, 128 KB each) and count themselves in (kflag);
+    // the last part -- the highest workgroup index of the P, dispatched after the others -- waits for the count, adds the
+    // partial outputs and stores the item.  A split item is always its workgroup's last.
     const int ntbx = (ntb + 7) / 8;
     const int xcd = blockIdx.x % 8, jx = blockIdx.x / 8, gx = gridDim.x / 8;
     const int llen = ntbx * NCB;
-    const int ni = jx < llen ? (llen - jx + gx - 1) / gx : 0;      // items of this workgroup
+    const int R = llen / gx, rem = llen - R * gx;
+    int P = 1;
+    if (SPLIT && rem > 0) {   // (SPLIT = false: the launcher found no split worth its exchange; the left-over items run whole)
+        const int cap = min(min(gx / rem, 8), NC / 4);
+        while (2 * P <= cap) P *= 2;
+    }
+    const bool has_tail = jx < rem * P;
+    const int ni = R + (has_tail ? 1 : 0);                          // items of this workgroup
     if (ni == 0) return;
-    const int Q = ni * NC;                                          // chunks of this workgroup, all items
+    const int CPT = NC / P;                                         // chunks of a part
+    const int Q = R * NC + (has_tail ? CPT : 0);                    // chunks of this workgroup, all items
 
-    struct Item { int cob, n0, band; };
+    struct Item { int cob, n0, band, c0, c1, part; };
     auto item_at = [&](int i) {
-        const int p = jx + i * gx;
+        const bool last = i == R;                                   // the (possibly split) left-over item
+        const int p = last ? R * gx + jx / P : jx + i * gx;
         Item it;
+        it.part = last ? jx % P : 0;
+        it.c0 = last ? it.part * CPT : 0;
+        it.c1 = last ? it.c0 + CPT : NC;
         it.cob = COB_MAJOR ? p / ntbx : p % NCB;
         const int tbk = (COB_MAJOR ? p % ntbx : p / NCB) * 8 + xcd;   // tile blocks past ntb: patches >= N, nothing is stored
         it.n0 = PB > 1 ? tbk * PB : tbk / BPP;
@@ -661,9 +682,11 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         // ---- staging state (waves 4..7)
         const float* in_item = in;
         unsigned voff[NIN];
-        int in_i = 0, in_c = 0;                                 // (item, chunk) the input stream issues next
+        int in_i = 0, in_c = 0, in_cend = NC;                   // (item, chunk) the input stream issues next; the item's last chunk + 1
         auto set_input_item = [&](int i) {
             const Item it = item_at(i);
+            in_c = it.c0;
+            in_cend = it.c1;
             const int nb = it.n0 < N ? it.n0 : 0;               // addressing stays inside the buffer for discarded items
             in_item = in + (size_t)nb * CIN * PLANE;
             const int y0 = it.band * 4 * TROWS;                  // first staged haloed row (= output row y0 - 1)
@@ -684,8 +707,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             LG_DMA16(in_c_ptr + voff[j], s_in + stage * STAGE + 4 * ((j * 4 + dw) * 64));
         };
         auto input_advance = [&]() {
-            if (++in_c == NC) {
-                in_c = 0;
+            if (++in_c == in_cend) {
                 if (++in_i < ni) set_input_item(in_i);
             }
         };
@@ -793,7 +815,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < NIN; j++) input_piece(j, 0);
             input_advance();
-            const float* ablk0 = U4 + (size_t)item_at(0).cob * ABLK;
+            const float* ablk0 = U4 + (size_t)item_at(0).cob * ABLK + (size_t)item_at(0).c0 * NCB * ABLK;
 #pragma unroll
             for (int j = 0; j < 9; j++) a_piece(j, ablk0, 0);
         }
@@ -810,7 +832,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < NIN; j++) input_piece(j, 1);
                 input_advance();
-                const float* ablk1 = U4 + (size_t)item_at(0).cob * ABLK + (size_t)NCB * ABLK;   // (NC >= 3: chunk 1 is item 0's)
+                const float* ablk1 = U4 + (size_t)item_at(0).cob * ABLK + (size_t)(item_at(0).c0 + 1) * NCB * ABLK;   // (an item has >= 3 chunks: chunk 1 is item 0's)
 #pragma unroll
                 for (int j = 0; j < 9; j++) a_piece(j, ablk1, 1);
             }
@@ -849,13 +871,15 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
         f32x4 acc[36];
 #pragma unroll
         for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[item_at(0).cob * 64 + 16 * cb + 4 * (lane >> 4)]);
+        if (item_at(0).part == 0)   // (the bias enters once: through the part that holds the first chunks)
+            acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[item_at(0).cob * 64 + 16 * cb + 4 * (lane >> 4)]);
 #pragma unroll 1
         for (int it_i = 0; it_i < ni; it_i++) {
             const Item cur = item_at(it_i);
-            const int cob_next = it_i + 1 < ni ? item_at(it_i + 1).cob : cur.cob;
+            const Item nxt = it_i + 1 < ni ? item_at(it_i + 1) : cur;
+            const int cob_next = nxt.cob;
 #pragma unroll 1
-            for (int c = 0; c < NC; c++, q++) {
+            for (int c = cur.c0; c < cur.c1; c++, q++) {
                 const int st = q & 1;                           // A / V stage of this chunk
                 const int in_next = NSTG == 3 ? (q + 1) % 3 : st ^ 1;   // input stage holding chunk q + 1 (transformed now)
                 const int in_free = NSTG == 3 ? q % 3 : st;             // input stage the staging waves refill (chunk q + NSTG)
@@ -912,7 +936,7 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     // U(q + 1) (asked for right after the previous barrier) and everything older have landed; what may stay in
                     // flight is younger: the NIN input transfers above (3-stage ring) and, in an item's first chunk, the previous
                     // item's plane stores
-                    const bool keep_in = NSTG == 3 && more2, keep_st = NSTG == 3 && c == 0 && prev_full;
+                    const bool keep_in = NSTG == 3 && more2, keep_st = NSTG == 3 && c == cur.c0 && prev_full;
                     // (the vmcnt waits carry no register operands: tying the fragment registers to four alternative asm statements made
                     //  hipcc copy them -- destinations of LDS reads still in flight -- in front of the wait)
                     if (keep_in && keep_st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SCNT + NIN) : "memory");
@@ -921,8 +945,8 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]), "+v"(fa[2]), "+v"(fb[2])::"memory");
                     if (q + 2 < Q) {                             // the U block two chunks ahead into the stage this chunk has just released
-                        const bool same = c + 2 < NC;
-                        const float* ablk = U4 + (size_t)(same ? cur.cob : cob_next) * ABLK + (size_t)(same ? c + 2 : c + 2 - NC) * NCB * ABLK;
+                        const bool same = c + 2 < cur.c1;
+                        const float* ablk = U4 + (size_t)(same ? cur.cob : cob_next) * ABLK + (size_t)(same ? c + 2 : c + 2 - cur.c1 + nxt.c0) * NCB * ABLK;
 #pragma unroll
                         for (int k = 0; k < 9; k++) a_piece(k, ablk, st);
                     }
@@ -948,13 +972,8 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
             const int epb = etau / TPB, etl = etau % TPB;
             const int n = cur.n0 + epb;
             const int trg = cur.band * TROWS + etl / TC, tcg = etl % TC;
-            if (LG_W4_EXP & 64) {
-#pragma unroll
-                for (int p = 0; p < 36; p++) asm volatile("" ::"v"(acc[p]));
-            } else
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
+            // output transform of channel row r: 36 accumulator components -> the tile's 4 x 4 outputs (before ReLU)
+            auto out_transform = [&](int r, float (&y)[4][4]) {
                 float s[4][6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
@@ -966,7 +985,6 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     s[2][j] = fmaf(4.f, t3, t1);
                     s[3][j] = fmaf(8.f, t4, t2) + m5;
                 }
-                float y[4][4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const float t1 = s[p][1] + s[p][2], t2 = s[p][1] - s[p][2], t3 = s[p][3] + s[p][4], t4 = s[p][3] - s[p][4];
@@ -975,6 +993,10 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                     y[p][2] = fmaf(4.f, t3, t1);
                     y[p][3] = fmaf(8.f, t4, t2) + s[p][5];
                 }
+            };
+            // ReLU (+ 2 x 2 max-pool) and the stores of channel row r
+            auto out_store = [&](int r, const float (&y)[4][4]) {
+                const int co = cur.cob * 64 + 16 * cb + 4 * (lane >> 4) + r;
                 if ((LG_W4_EXP & 256) || ((LG_W4_EXP & 2048) && !IS_T) || ((LG_W4_EXP & 4096) && IS_T)) {
 #pragma unroll
                     for (int p = 0; p < 4; p++) asm volatile("" ::"v"(y[p][0]), "v"(y[p][1]), "v"(y[p][2]), "v"(y[p][3]));
@@ -1028,12 +1050,75 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                         if (trg == TC - 1) edge_row(o + WO * OP);
                     }
                 }
+            };
+            if (LG_W4_EXP & 64) {
+#pragma unroll
+                for (int p = 0; p < 36; p++) asm volatile("" ::"v"(acc[p]));
+            } else if (SPLIT && NC >= 8 && P > 1 && it_i == R) {   // a split item (wave-uniform; both roles, all eight waves)
+                // The output transform is linear: every part transforms ITS partial sums, and what travels is the 16 outputs
+                // per channel and tile instead of the 36 accumulators (128 KB per part instead of 288), in registers the
+                // accumulators have left free -- all 16 loads of a part are in flight at once.
+                // The parts of an item run on one XCD and meet in ITS L2: no cache maintenance, only order.  (Agent-scope fences
+                // -- __threadfence, release / acquire -- write the XCD's dirty lines back, megabytes of just-stored activations:
+                // measured, they cost more than the split saves.)  A part's stores are acknowledged by the L2 (vmcnt 0) before
+                // it counts itself in; the owner's compute unit has not read these addresses in this launch (its L1 was
+                // invalidated when the kernel started), so its loads come from the L2.
+                float yv[4][4][4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    out_transform(r, yv[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // [workgroup][channel row x tile row (16)][wave][lane] 16 bytes: a wave instruction moves 1 KB
+                f32x4* mine = reinterpret_cast<f32x4*>(kpart) + (size_t)blockIdx.x * (16 * 512) + t;
+                asm volatile("" : "+v"(mine));   // (opaque: hipcc otherwise forms the addresses in front of the item loop and spills them)
+                if (cur.part != P - 1) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) mine[e * 512] = (f32x4){yv[e >> 2][e & 3][0], yv[e >> 2][e & 3][1], yv[e >> 2][e & 3][2], yv[e >> 2][e & 3][3]};
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (t == 0) __hip_atomic_fetch_add(&kflag[blockIdx.x + 8 * (P - 1 - cur.part)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;              // no stores, and no further item
+                }
+                if (t == 0) {
+                    // (the parts have lower workgroup indices on this XCD: dispatched before this one, they are running or done.
+                    //  Should that ever not hold, the launch fails after ~0.5 s instead of waiting for ever.)
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&kflag[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(P - 1)) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 22)) __builtin_trap();
+                    }
+                    __hip_atomic_store(&kflag[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch; every part has counted itself in)
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+                for (int k = 1; k < P; k++) {
+                    const f32x4* theirs = mine - (size_t)(8 * k) * (16 * 512);   // workgroup jx - k of this XCD
+                    asm volatile("" : "+v"(theirs));
+                    f32x4 tmp[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) tmp[e] = __builtin_nontemporal_load(theirs + e * 512);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) yv[e >> 2][e & 3][j] += tmp[e][j];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    out_store(r, yv[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float y[4][4];
+                out_transform(r, y);
+                out_store(r, y);
                 __builtin_amdgcn_sched_barrier(0);   // one channel row at a time: keeps the transform temporaries of the 4 rows apart
             }
             prev_full = cur.n0 + PB <= N;            // every lane of this wave stored (n < N): the SCNT stores above were issued
 #pragma unroll
             for (int p = 0; p < 36; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[cob_next * 64 + 16 * cb + 4 * (lane >> 4)]);
+            if (nxt.part == 0) acc[7] = *reinterpret_cast<const f32x4*>(&s_bias[cob_next * 64 + 16 * cb + 4 * (lane >> 4)]);
         }
     };
     if (wave < 4) role(std::true_type{});
@@ -1202,26 +1287,49 @@ bool launch_wino_rt(int cin, int cout, int wi, bool pool, bool out_halo, const f
 
 #define LG_WINO4_L0_SHAPES(X) X(12, 64, 32, false) X(12, 128, 32, false)
 // max_cus > 0: workgroups (= CUs) the persistent F(4x4) kernels may take (LgCnn::max_cus, the LG_CNN_CUS experiment)
-bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
-                     float* out, int N, int max_cus, hipStream_t s) {
-    const int tp = (wi / 4) * (wi / 4);
-    const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
-    // persistent: one 512-thread workgroup per CU (140-156 KB of LDS each), a multiple of 8 so every XCD gets the same number
+// workgroups of the persistent F(4x4) kernels, at most (= CUs; a multiple of 8 so every XCD gets the same number)
+static int lg_w4_num_cu() {
     static const int num_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n >= 8 ? n / 8 * 8 : 8;
     }();
+    return num_cu;
+}
+constexpr size_t LG_W4_KPART_FLOATS = 16 * 512 * 4;   // partial outputs of one workgroup (lg_wino4_kernel, split items)
+
+bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
+                     float* out, int N, int max_cus, float* kpart, unsigned* kflag, hipStream_t s) {
+    const int tp = (wi / 4) * (wi / 4);
+    const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
+    // persistent: one 512-thread workgroup per CU (140-156 KB of LDS each)
+    const int num_cu = lg_w4_num_cu();
     const long long items8 = (long long)((ntb + 7) / 8) * (cout / 64);   // items per XCD
     const int cus = max_cus > 0 ? std::max(8, std::min(num_cu, max_cus / 8 * 8)) : num_cu;
-    const int grid = 8 * (int)std::min<long long>(items8, cus / 8);
-#define X(CI, CO, W_, P)                                                                                              \
-    if (cin == CI && cout == CO && wi == W_ && pool == P) {                                                           \
+    // Left-over items (fewer items than workgroups, or a last round that fills only some of them) are split along the input
+    // channels over P workgroups each -- when that pays: the parts' exchange costs ~18 (P = 4) to ~26 us (P = 8), a part saves
+    // (1 - 1/P) of an item's cin / 4 chunks of ~1.1 us (measured per layer at 20 and 640 patches, profiles/r04_cnn_split_items.txt:
+    // 256 -> 256 channels halves at one frame and gains 18 % at 640 patches; 64-channel layers lose).
+    int gx = cus / 8, P = 1;
+    const int rem = items8 < gx ? (int)items8 : (int)(items8 % gx);
+    if (rem > 0) {
+        const int cap = std::min(std::min(gx / rem, 8), cin / 16);
+        while (2 * P <= cap) P *= 2;
+    }
+    const bool split = P > 1 && (cin / 4) * (P - 1) / P >= 26;
+    if (items8 < gx) gx = (int)items8 * (split ? P : 1);
+    const int grid = 8 * gx;
+#define X(CI, CO, W_, P_)                                                                                             \
+    if (cin == CI && cout == CO && wi == W_ && pool == P_) {                                                          \
         constexpr bool CM = 36LL * CI * CO * 4 > 3 * 1024 * 1024;                                                     \
-        if (out_halo)                                                                                                 \
-            hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P, true, CM>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb);  \
-        else                                                                                                          \
-            hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P, false, CM>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb); \
+        constexpr bool CAN = CI >= 128;   /* (cin / 4 * 7 / 8 >= 26) */                                              \
+        if (out_halo) {                                                                                               \
+            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+        } else {                                                                                                      \
+            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+        }                                                                                                             \
         return true;                                                                                                  \
     }
     LG_WINO_SHAPES(X)
@@ -1237,7 +1345,8 @@ void lg_cnn_free(LgCnn* c) {
     for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); F(c->uwino4[i]); F(c->act[i]); }
     F(c->att_w); F(c->ca_w1); F(c->ca_b1); F(c->ca_w2); F(c->ca_b2);
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
-    F(c->in_halo); F(c->zeros);
+    F(c->in_halo); F(c->zeros); F(c->kpart);
+    if (c->kflag) { hipFree(c->kflag); c->kflag = nullptr; }
     c->capN = 0;
     c->loaded = false;
 }
@@ -1426,6 +1535,15 @@ size_t lg_cnn_halo_patch_floats(void) { return (size_t)12 * lg_plane(32); }
 
 // activation buffers, one per layer (fixed geometry: the zero halos are written once, at allocation)
 static int ensure_act(LgCnn* c, int N, hipStream_t s, std::string* err) {
+    if (!c->kpart) {   // partial sums + counters of the split items of lg_wino4_kernel (one slot per workgroup; the kernel resets its counters)
+        const size_t wg = (size_t)lg_w4_num_cu();
+        if (hipMalloc((void**)&c->kpart, wg * LG_W4_KPART_FLOATS * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&c->kflag, wg * sizeof(unsigned)) != hipSuccess ||
+            hipMemsetAsync(c->kflag, 0, wg * sizeof(unsigned), s) != hipSuccess) {
+            *err = "lg_cnn_forward: workspace allocation failed";
+            return LG_ERR_NOMEM;
+        }
+    }
     if (N <= c->capN) return LG_OK;
     hipStreamSynchronize(s);
     for (int i = 0; i < 8; i++)
@@ -1476,7 +1594,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
     }
     // layer 0: the F(4x4,3x3) kernel on 12 input planes (3 chunks); the direct 9-channel kernel with LG_CNN_DIRECT / _F23 / mask bit 0 clear
     if (!c->use_f23 && (c->wino_mask & 1) &&
-        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, c->max_cus, s)) {
+        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, c->max_cus, c->kpart, c->kflag, s)) {
         // (a shape the F(4x4) table lacks falls through to the direct kernel instead of leaving act[0] unwritten)
     } else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
     else launch_conv0<128>(x, c, c->act[0], N, s);
@@ -1488,7 +1606,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         const RtLayer& l = c->layers[L];                                                                            \
         if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, c->act[L], N, s);                               \
         else if (c->use_f23) launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
-        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, s); \
+        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, s); \
         cur = c->act[L];                                                                                            \
     } while (0)
         LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
@@ -1501,7 +1619,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         for (int L = 1; L < c->n_layers; L++) {
             const RtLayer& l = c->layers[L];
             const bool okl = c->use_f23 ? launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)
-                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, s);
+                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, s);
             if (!okl) {
                 *err = "lg_cnn_forward: unsupported layer shape";
                 return LG_ERR_UNSUPPORTED;
