@@ -182,7 +182,7 @@ def test_windowed_sweeps_are_exact(dt_sels, form):
     assert n_windowed >= 20   # the windowed path was actually exercised
 
 
-@pytest.mark.parametrize("form", ["search1", "search2_np4", "search2_np1"])
+@pytest.mark.parametrize("form", ["auto", "search1", "search2_np4", "search2_np1"])
 def test_row_search_on_hard_masks(dt_sels, form):
     """Masks the row search has to get right beyond the window cases: a frame with a single zero pixel, full-width bands (rows
     without any zero pixel), leaves wider than 64 words' worth of columns is covered at 4K; thin diagonal strips (every
@@ -220,6 +220,18 @@ def test_row_search_on_hard_masks(dt_sels, form):
     for i in range(len(masks)):
         np.testing.assert_array_equal(mb["distance_map"][i].cpu().numpy(), exp[i], err_msg=f"batched mask {i}")
         assert sel.dt_maxima(i)[0] == exp[i].max(), f"batched mask {i}"
+    if form == "auto":
+        # search or sweeps is decided per BATCH from sums over its frames (lg_bbox_kernel): twenty times the batch is past the
+        # budget -- every frame is swept --, the small batch after it is searched again (the kernel resets its own sums)
+        big = [masks[i % len(masks)] for i in range(20 * len(masks))]
+        mb, _, _ = sel.score_maps(torch.from_numpy(np.stack(big)).cuda(), torch.from_numpy(np.stack([depth] * len(big))).cuda())
+        for i in range(0, len(big), 7):
+            np.testing.assert_array_equal(mb["distance_map"][i].cpu().numpy(), exp[i % len(masks)], err_msg=f"big batch, frame {i}")
+            assert sel.dt_maxima(i)[0] == exp[i % len(masks)].max(), f"big batch, frame {i}"
+        del mb
+        ms, _, _ = sel.score_maps(torch.from_numpy(np.stack(masks[:5])).cuda(), torch.from_numpy(np.stack([depth] * 5)).cuda())
+        for i in range(5):
+            np.testing.assert_array_equal(ms["distance_map"][i].cpu().numpy(), exp[i], err_msg=f"small batch after the big one, mask {i}")
 
 
 def test_chamfer_init_dist0_is_a_parameter(L):
