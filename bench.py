@@ -104,17 +104,21 @@ def final_kernel_bytes(masks_np, wins, H, W, tile_w=64, tile_h=16):
     return total
 
 
-def kernel_fracs(kern_ms, masks_np, wins, B, H, W, K=20):
+def kernel_fracs(kern_ms, masks_np, wins, B, H, W, K=20, forms=None):
     """Compulsory HBM bytes (read once + written once) of ONE launch of every score-path kernel beside the
     plane kernel, for these masks, its average duration and the fraction of the 8 TB/s peak that makes.  Latency-bound kernels
     (one workgroup per frame, bit rows only) show as the small fractions they are.  `wins[i]` = (x0, x1, y0, y1): frame i's
-    distance-transform window as the library reports it (lg_debug_dt_max).  kern_ms: name -> average ms."""
+    distance-transform window as the library reports it (lg_debug_dt_max); `forms[i]` = (searched, d_out sweeps skipped) as it
+    reports them (lg_debug_dt_form): a searched frame's sweeps and a swept frame's search kernels move nothing.  A kernel that
+    moved nothing in this batch (launched, every frame exits) is left out.  kern_ms: name -> average ms."""
     nd = len(masks_np)
     WW = (W + 63) // 64
     bits = H * WW * 8                               # one frame's bit rows
     per = {k: 0.0 for k in ("prep", "bbox", "stem", "orient", "dt_hrun", "dt_search", "dt_band", "dt_fwd", "dt_bwd", "dt_border",
                             "topk", "gather")}
-    for m, (wx0, wx1, wy0, wy1) in zip(masks_np, wins):
+    if forms is None:
+        forms = [(False, False)] * nd
+    for m, (wx0, wx1, wy0, wy1), (searched, skip_out) in zip(masks_np, wins, forms):
         ys, xs = np.nonzero(m)
         win_px = (wx1 - wx0) * (wy1 - wy0)
         if ys.size:
@@ -127,20 +131,22 @@ def kernel_fracs(kern_ms, masks_np, wins, B, H, W, K=20):
         per["orient"] += bb_rows * bb_words * 8
         per["dt_border"] += bb_rows * bb_words * 8
         # row search: run distances (2 B per pixel of the bounding box's words) written once, read once; distance_map written
-        per["dt_hrun"] += bb_rows * bb_words * (8 + 128)
-        if "dt_band" in kern_ms:                    # anchors (every 8th row: distance + minimising row) / the rows between
-            per["dt_search"] += bb_rows * bb_words * 128 // 8 + win_px * (4 + 2) // 8
-            per["dt_band"] += bb_rows * bb_words * 128 + win_px * 2 // 8 + win_px * 4 * 7 // 8
-        else:
-            per["dt_search"] += bb_rows * bb_words * 128 + win_px * 4
-        per["dt_fwd"] += win_px * (1 + 4)           # sweeps (frames that take them): mask in, forward values out; those in, distance out
-        per["dt_bwd"] += win_px * (4 + 4)
+        if searched:
+            per["dt_hrun"] += bb_rows * bb_words * (8 + 128)
+            if "dt_band" in kern_ms:                # anchors (every 8th row: distance + minimising row) / the rows between
+                per["dt_search"] += bb_rows * bb_words * 128 // 8 + win_px * (4 + 2) // 8
+                per["dt_band"] += bb_rows * bb_words * 128 + win_px * 2 // 8 + win_px * 4 * 7 // 8
+            else:
+                per["dt_search"] += bb_rows * bb_words * 128 + win_px * 4
+        n_sweeps = (0 if searched else 1) + (0 if skip_out else 1)    # d_in and d_out images this frame's sweeps work on
+        per["dt_fwd"] += n_sweeps * win_px * (1 + 4)   # mask in, forward values out; those in, distance out
+        per["dt_bwd"] += n_sweeps * win_px * (4 + 4)
         tiles = ((W + 63) // 64) * ((H + 15) // 16)
         per["topk"] += tiles * 8 + K * 8 * 1024 * 5  # tile keys + the <= 8 tiles a pick's suppression window touches (score + valid)
         per["gather"] += K * (9 * 32 * 32 * 4 + 12 * 34 * 36 * 4)
     out = {}
     for k, tot in per.items():
-        if k in kern_ms and kern_ms[k] > 0:
+        if k in kern_ms and kern_ms[k] > 0 and tot > 0:
             b = tot * (B / nd)
             out[k] = {"bytes": round(b), "avg_ms": round(kern_ms[k], 4), "frac": round(b / (kern_ms[k] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
     return out
@@ -508,7 +514,12 @@ def main():
         try:   # every other kernel of the path: compulsory bytes, average duration, fraction of the HBM peak
             n_distinct = min(B, N_DISTINCT)
             wins_k = [sels[0].dt_maxima(i)[2] for i in range(n_distinct)]
-            out["kernel_fracs"] = kernel_fracs({k: v["avg_ms"] for k, v in kern.items()}, masks_np[:n_distinct], wins_k, B, H, W)
+            forms_k = [sels[0].dt_form(i) for i in range(n_distinct)]
+            out["kernel_fracs"] = kernel_fracs({k: v["avg_ms"] for k, v in kern.items()}, masks_np[:n_distinct], wins_k, B, H, W,
+                                               forms=forms_k)
+            out["kernel_fracs"]["dt_form"] = {"searched_frames": sum(f[0] for f in forms_k), "d_out_sweeps_skipped": sum(f[1] for f in forms_k),
+                                              "of": n_distinct, "what": "which form of the distance transform the batch took (decided on "
+                                                                        "the device, lg_bbox_kernel): row search or the two sweeps"}
         except Exception as e:  # noqa: BLE001
             out["kernel_fracs"] = {"error": str(e)}
         if "cnn" in kern and not args.no_cnn:

@@ -266,6 +266,9 @@ int lg_profile_read(lg_handle h, const char* name, int* launches, double* total_
    max|d_in - d_out| of calculate_sdf_score, grasp_point_selector.py:531-533, is their maximum / 65536);
    win[0..3] (optional) = the distance-transform sweep window {x0, x1, y0, y1} (half open) used for that frame. */
 int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]);
+/* form[0] = 1: d_in of that frame came from the row search (0: from the two sweeps); form[1] = 1: its d_out sweeps were
+   skipped (the maximum provably lies on the frame border).  Which form a batch takes is decided on the device. */
+int lg_debug_dt_form(lg_handle h, int frame, int32_t form[2]);
 
 /* ---- GraspPointCNN training step: one call = one iteration of the inner loop of
    scripts/train_model.py:247-265 (zero_grad, forward in train mode, BCEWithLogitsLoss(pos_weight), backward,

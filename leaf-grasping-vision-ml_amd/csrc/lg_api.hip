@@ -456,6 +456,19 @@ int lg_debug_dt_max(lg_handle h, int frame, uint32_t out[2], int32_t win[4]) {
     return LG_OK;
 }
 
+int lg_debug_dt_form(lg_handle h, int frame, int32_t form[2]) {
+    if (!h || !form || frame < 0 || frame >= h->capB || !h->win) return LG_ERR_INVALID;
+    LG_ENTER(h);
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    LgWin w;
+    if (hipMemcpy(&w, h->win + frame, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, LG_ERR_HIP, "lg_debug_dt_form: copy failed");
+    form[0] = w.search_in ? 1 : 0;
+    form[1] = w.skip_out ? 1 : 0;
+    return LG_OK;
+}
+
 }  // extern "C"
 
 namespace {

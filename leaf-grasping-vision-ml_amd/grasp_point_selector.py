@@ -174,6 +174,16 @@ class GraspPointSelector:
         scale = np.float32(1.0 / 65536.0)
         return np.float32(out[0]) * scale, np.float32(out[1]) * scale, tuple(win)
 
+    def dt_form(self, frame=0):
+        """Inspection: (searched, d_out sweeps skipped) of `frame` in the last call -- whether its d_in came from the row search
+        or from the two sweeps is decided per batch on the device."""
+        import ctypes as C
+        form = (C.c_int32 * 2)()
+        rc = lib.lg_debug_dt_form(self._h, int(frame), form)
+        if rc != 0:
+            raise RuntimeError(lib.lg_last_error(self._h).decode())
+        return bool(form[0]), bool(form[1])
+
     def _calculate_all_scores(self, leaf_mask_np, depth_tensor, image_processor=None):
         """Reference signature (:256): numpy uint8 mask in, dict of numpy planes out."""
         out, _, _ = self.score_maps(leaf_mask_np, depth_tensor, image_processor)

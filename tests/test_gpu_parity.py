@@ -228,8 +228,10 @@ def test_row_search_on_hard_masks(dt_sels, form):
         for i in range(0, len(big), 7):
             np.testing.assert_array_equal(mb["distance_map"][i].cpu().numpy(), exp[i % len(masks)], err_msg=f"big batch, frame {i}")
             assert sel.dt_maxima(i)[0] == exp[i % len(masks)].max(), f"big batch, frame {i}"
+        assert not any(sel.dt_form(i)[0] for i in range(0, len(big), 7)), "a batch past the budget is swept"
         del mb
         ms, _, _ = sel.score_maps(torch.from_numpy(np.stack(masks[:5])).cuda(), torch.from_numpy(np.stack([depth] * 5)).cuda())
+        assert all(sel.dt_form(i)[0] for i in range(5)), "a small batch is searched"
         for i in range(5):
             np.testing.assert_array_equal(ms["distance_map"][i].cpu().numpy(), exp[i], err_msg=f"small batch after the big one, mask {i}")
 
