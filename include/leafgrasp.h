@@ -197,6 +197,12 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                     const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
                     lg_grasp_result* results, void* stream);
 
+/* The node's result message of every frame (leaf_grasp_node_v3.py:170-176: "x,y,X,Y,Z[,pX,pY,pZ]", each number as Python's
+   str() prints it -- the shortest decimal string of the float32 value as a double), '\n'-terminated, one line per frame in
+   order, an empty line for a frame without a result.  buf: HOST, cap bytes (>= 256 per frame); *used = bytes written.
+   No device work; needs no handle. */
+int lg_format_grasp_results(const lg_grasp_result* results, int n, char* buf, int64_t cap, int64_t* used);
+
 /* Per-label statistics + clutter extrema for one frame.  labels [H][W] int16 DEVICE, depth DEVICE.
    stats: HOST array of capacity max_leaves; n_leaves: HOST.  extrema (HOST, 4 ints): first leaf
    pixel (y,x) and the background pixel farthest (exact Euclidean) from any leaf (y,x). */

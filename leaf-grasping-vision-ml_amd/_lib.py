@@ -89,6 +89,7 @@ SYMBOLS = {
     "lg_profile_enable": (C.c_int, [_VP, C.c_int]),
     "lg_profile_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "lg_debug_dt_max": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "lg_format_grasp_results": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     "lg_debug_dt_form": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int32)]),
     "lg_harvest_patches": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "lg_negative_masks": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP]),

@@ -300,3 +300,89 @@ int lg_host_contour_points(const unsigned long long* bits, int H, int W, int WW,
     outer_border_area(bits, H, W, WW, 0, WW - 1, runs[best_root].x0, runs[best_root].y, &xy);
     return (int)(xy.size() / 2);
 }
+
+// ---- the node's result message (leaf_grasp_node_v3.py:170-176): "x,y,X,Y,Z[,pX,pY,pZ]" with Python's str() of every number.
+// For the floats that is repr(float(np.float32)): the SHORTEST decimal string that reads back as the same double, in fixed
+// notation while -4 <= exponent < 16 (always with a fractional part: "5.0") and as d[.ddd]e+XX (at least two exponent digits)
+// outside -- CPython's float_repr_style 'short'.  std::to_chars yields the same shortest digits (both pick the closest of the
+// shortest candidates); the layout rules are applied here.  One '\n'-terminated line per frame, empty when nothing was found.
+#include <charconv>
+#include <cstring>
+
+#include "../../include/leafgrasp.h"
+
+namespace {
+char* put_py_float(char* p, float f32) {
+    const double v = (double)f32;
+    if (v != v) { memcpy(p, "nan", 3); return p + 3; }
+    if (v == HUGE_VAL) { memcpy(p, "inf", 3); return p + 3; }
+    if (v == -HUGE_VAL) { memcpy(p, "-inf", 4); return p + 4; }
+    char tmp[40];
+    const std::to_chars_result r = std::to_chars(tmp, tmp + sizeof(tmp), v, std::chars_format::scientific);
+    const char* q = tmp;
+    if (*q == '-') *p++ = *q++;
+    char dig[24];
+    int nd = 0;
+    for (; q < r.ptr && *q != 'e'; q++)
+        if (*q != '.') dig[nd++] = *q;
+    int e10 = 0;
+    {
+        q++;   // 'e'
+        const bool neg = *q == '-';
+        q++;   // sign
+        for (; q < r.ptr; q++) e10 = 10 * e10 + (*q - '0');
+        if (neg) e10 = -e10;
+    }
+    if (nd == 1 && dig[0] == '0') e10 = 0;   // 0.0 / -0.0
+    if (e10 < -4 || e10 >= 16) {             // d[.ddd]e+XX
+        *p++ = dig[0];
+        if (nd > 1) { *p++ = '.'; memcpy(p, dig + 1, nd - 1); p += nd - 1; }
+        *p++ = 'e';
+        *p++ = e10 < 0 ? '-' : '+';
+        const int a = e10 < 0 ? -e10 : e10;
+        if (a >= 100) *p++ = (char)('0' + a / 100);
+        *p++ = (char)('0' + (a / 10) % 10);
+        *p++ = (char)('0' + a % 10);
+    } else if (e10 < 0) {                    // 0.000ddd
+        *p++ = '0'; *p++ = '.';
+        for (int i = 0; i < -e10 - 1; i++) *p++ = '0';
+        memcpy(p, dig, nd); p += nd;
+    } else {                                 // ddd.ddd / ddd000.0
+        const int ni = e10 + 1;
+        for (int i = 0; i < ni; i++) *p++ = i < nd ? dig[i] : '0';
+        *p++ = '.';
+        if (nd > ni) { memcpy(p, dig + ni, nd - ni); p += nd - ni; }
+        else *p++ = '0';
+    }
+    return p;
+}
+char* put_int(char* p, int v) {
+    const std::to_chars_result r = std::to_chars(p, p + 12, v);
+    return r.ptr;
+}
+}  // namespace
+
+extern "C" int lg_format_grasp_results(const lg_grasp_result* res, int n, char* buf, int64_t cap, int64_t* used) {
+    if (!res || n < 0 || !buf || !used) return LG_ERR_INVALID;
+    char* p = buf;
+    char* const end = buf + cap;
+    for (int i = 0; i < n; i++) {
+        if (end - p < 8 * 32) return LG_ERR_INVALID;   // (a line is at most 2 x 11 + 6 x 25 + 8 characters)
+        const lg_grasp_result& r = res[i];
+        if (r.found) {
+            p = put_int(p, r.x); *p++ = ',';
+            p = put_int(p, r.y); *p++ = ',';
+            p = put_py_float(p, r.X); *p++ = ',';
+            p = put_py_float(p, r.Y); *p++ = ',';
+            p = put_py_float(p, r.Z);
+            if (r.has_pre) {
+                *p++ = ','; p = put_py_float(p, r.pX);
+                *p++ = ','; p = put_py_float(p, r.pY);
+                *p++ = ','; p = put_py_float(p, r.pZ);
+            }
+        }
+        *p++ = '\n';
+    }
+    *used = p - buf;
+    return LG_OK;
+}

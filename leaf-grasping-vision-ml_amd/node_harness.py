@@ -47,6 +47,20 @@ class LeafGraspHarness:
                     f"{pre_grasp_point[0]},{pre_grasp_point[1]},{pre_grasp_point[2]}")
         return f"{grasp_point_2d[0]},{grasp_point_2d[1]},{grasp_point_3d[0]},{grasp_point_3d[1]},{grasp_point_3d[2]}"
 
+    @staticmethod
+    def format_results(results, n):
+        """format_result for the first n rows of an lg_grasp_result array (lg_format_grasp_results): a list of n strings, None
+        where a frame has no result."""
+        import ctypes as C
+
+        from ._lib import LgError, lib
+        buf = C.create_string_buffer(256 * max(1, n))
+        used = C.c_int64(0)
+        rc = lib.lg_format_grasp_results(results, n, buf, len(buf), C.byref(used))
+        if rc != 0:
+            raise LgError(f"lg_format_grasp_results failed with status {rc}")
+        return [ln if ln else None for ln in C.string_at(buf, used.value).decode().split("\n")[:n]]
+
     def select_optimal_leaf(self):         # :102-158
         """Returns the CSV string the node would publish on /optimal_leaf_grasp, or None."""
         if self.latest_mask is None or self.latest_depth is None:
@@ -136,7 +150,8 @@ class LeafGraspHarness:
         else:
             sel = torch.tensor(keep, device=self.device)
             optimal, dep = mask_t.index_select(0, sel) == idt, depth_t.index_select(0, sel)
-        res = self.grasp_selector.select_grasp_points_batch(optimal, dep, image_processor=self.image_processor)
-        for b, (p2, p3, pre) in zip(keep, res):
-            if p2 is not None:
-                out[offset + b] = self.format_result(p2, p3, pre)
+        self.grasp_selector.select_grasp_points_batch(optimal, dep, image_processor=self.image_processor)
+        # the messages of the whole chunk in one native call (format_result's strings, character for character: Python's float
+        # repr costs 0.24 ms per 128 frames -- a third of a millisecond the device waits for)
+        for b, line in zip(keep, self.format_results(self.grasp_selector.last_results, len(keep))):
+            out[offset + b] = line

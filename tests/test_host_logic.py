@@ -297,3 +297,35 @@ def test_sharding_world_size_2_gloo(tmp_path, world):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert all(f"rank{r}ok" in out.stdout for r in range(world))
+
+
+def test_native_result_messages_equal_pythons_strings():
+    """lg_format_grasp_results writes the node's message (leaf_grasp_node_v3.py:170-176) for a whole batch: every float as
+    Python's str() prints float(np.float32) -- shortest round-trip digits, fixed notation for exponents -4 ... 15, "5.0", "1e-05",
+    "1e+16", nan, inf.  Held against LeafGraspHarness.format_result (the f-string of the reference) on random bit patterns,
+    typical metric values and the special cases; no device work."""
+    import ctypes as C
+
+    from leafgrasp_amd.grasp_point_selector import LgGraspResult
+    from leafgrasp_amd.node_harness import LeafGraspHarness
+
+    rng = np.random.default_rng(0)
+    n = 40000
+    f = rng.integers(0, 2 ** 32, size=n * 6, dtype=np.uint64).astype(np.uint32).view(np.float32).reshape(n, 6).copy()
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 5.0, 100.0, 1e16, 1e15, 9999999.0, 1e-4, 1e-5, 123456.789, 3.4e38, 1.4e-45, np.inf,
+                   -np.inf, np.nan, 0.1, 0.5, 1e22, 16777216.0, 0.46686068177223206, 9.999999e15, 1.0000001e16, 0.00009999999], np.float32)
+    f[:len(sp), 0] = sp
+    f[:len(sp), 3] = sp[::-1]
+    f[1000:20000] = rng.normal(0, 0.3, size=(19000, 6)).astype(np.float32)
+    res = (LgGraspResult * n)()
+    a = np.frombuffer(res, dtype=np.dtype([(nm, np.int32 if t is C.c_int else np.float32) for nm, t in LgGraspResult._fields_]), count=n)
+    a["found"] = rng.integers(0, 5, n) > 0
+    a["x"], a["y"] = rng.integers(-5, 4000, n), rng.integers(0, 3000, n)
+    for i, k in enumerate(("X", "Y", "Z", "pX", "pY", "pZ")):
+        a[k] = f[:, i]
+    a["has_pre"] = rng.integers(0, 2, n)
+    got = LeafGraspHarness.format_results(res, n)
+    cols = [a[k].tolist() for k in ("found", "x", "y", "X", "Y", "Z", "has_pre", "pX", "pY", "pZ")]
+    for i, (fd, x, y, X, Y, Z, hp, pX, pY, pZ) in enumerate(zip(*cols)):
+        want = LeafGraspHarness.format_result((x, y), (X, Y, Z), (pX, pY, pZ) if hp else None) if fd else None
+        assert got[i] == want, (i, got[i], want)
