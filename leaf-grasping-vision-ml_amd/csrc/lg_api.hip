@@ -88,8 +88,6 @@ struct lg_ctx {
     std::atomic<bool> busy{false}; // one call in flight per handle (SURVEY 8b "Threading"): a concurrent second call gets LG_ERR_BUSY
     hipStream_t s_cnn = nullptr;   // LG_CNN_CUS=n: the CNN runs on a stream of its own restricted to n CUs (experiment: room for a second
     hipEvent_t ev_cnn0 = nullptr, ev_cnn1 = nullptr;   // batch's memory-bound kernels beside it, bench.py --inflight)
-    bool orient_inline = false;    // this call: lg_orient_kernel on the caller's stream, its status / result copies after the plane kernel (lg_select_grasp, <= 32 frames)
-    bool opt_orient_sync = false;  // LG_ORIENT_SYNC: lg_select_grasp waits for the device orientation's status words before it goes on
     bool opt_host_orient = false;  // LG_HOST_ORIENT: contour analysis of every frame on the host threads (the round-1 path)
 };
 
@@ -355,7 +353,6 @@ int lg_create(int device, lg_handle* out) {
     if (const char* e = getenv("LG_NO_SKIP")) h->opt_no_skip = std::max(1, atoi(e)) & 3;   // (both bits leave the results unchanged)
     h->opt_nt_stores = getenv("LG_NT_STORES") != nullptr;
     h->opt_host_orient = getenv("LG_HOST_ORIENT") != nullptr;
-    h->opt_orient_sync = getenv("LG_ORIENT_SYNC") != nullptr;
     if (const char* e = getenv("LG_DT_SEARCH")) h->opt_dt_search = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LG_DT_SEARCH_ALGO")) h->opt_dt_algo = std::max(0, std::min(4, atoi(e)));
     if (const char* e = getenv("LG_SIDE_TAIL")) h->opt_side_tail = std::max(0, std::min(2, atoi(e)));
@@ -525,17 +522,7 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     }
     LG_HIP(h, hipEventRecord(ev_prep, s));
     LG_HIP(h, hipStreamWaitEvent(h->copy_stream, ev_prep, 0));
-    if (h->orient && h->orient_inline) {
-        // Small calls are chains of latencies, and the orientation kernel (0.13 ms for one frame) is the longest link between the
-        // bit rows and the plane kernel.  On the side stream it paid two cross-queue hand-overs on top (~12 us in, ~23 us out: a
-        // kernel waiting for another queue's event starts that much after it); here it runs on the caller's stream, where the
-        // plane kernel follows it directly, the row search takes the side stream (enq_dt), and its results go to the host at the
-        // end of the call (enq_orient_results).
-        // First of everything that follows the bounding boxes: at this size the host's enqueue order is the device's start order
-        // (behind the search, the border maxima and the -- usually empty -- sweeps it started 50 us later).
-        ProfScope ps(h, "orient", s);
-        lg_launch_orient(h->orient, h->bits + off * words, h->win + off, h->fp_dev + off, off, n, pl.H, pl.W, pl.WW, s);
-    } else if (h->orient) {   // contour analysis on the device, beside the sweeps; the host reads theta / status back
+    if (h->orient) {   // contour analysis on the device, beside the sweeps; the host reads theta / status back
         {
             ProfScope ps(h, "orient", h->copy_stream);
             lg_launch_orient(h->orient, h->bits + off * words, h->win + off, h->fp_dev + off, off, n, pl.H, pl.W, pl.WW, h->copy_stream);
@@ -559,14 +546,6 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
         if (rc) return rc;
         LG_HIP(h, hipEventRecord(h->ev_side, ts));
     }
-    return LG_OK;
-}
-
-// orient_inline: the orientation kernel's results and status words to the host, behind whatever is queued on `s`
-int enq_orient_results(lg_ctx* h, int off, int n, hipStream_t s) {
-    LG_HIP(h, hipMemcpyAsync(h->fp_host + off, h->fp_dev + off, sizeof(LgFrameParams) * n, hipMemcpyDeviceToHost, s));
-    LG_HIP(h, hipMemcpyAsync(h->orient->h_status + off, h->orient->status + off, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-    LG_HIP(h, hipEventRecord(h->ev_orient, s));
     return LG_OK;
 }
 
@@ -594,7 +573,7 @@ int enq_dt(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s) {
     // d_in by the row search for the frames lg_bbox_kernel picked (LgWin::search_in), on a stream of its own beside the sweeps of
     // the other frames (and the d_out sweeps of the few frames that need them): throughput-bound work on every CU next to
     // latency-bound work on one workgroup per frame.  Inside the sub-batch pipeline (whose stages own the side streams): in line.
-    hipStream_t ss = (s == h->s_dt[0] || s == h->s_dt[1]) ? s : h->orient_inline ? h->copy_stream : h->s_dt[1];
+    hipStream_t ss = (s == h->s_dt[0] || s == h->s_dt[1]) ? s : h->s_dt[1];
     if (h->opt_dt_search) {
         if (ss != s) LG_HIP(h, hipStreamWaitEvent(ss, h->ev_prep, 0));
         {
@@ -677,7 +656,7 @@ int enq_final(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, bool upl
     const size_t px = (size_t)pl.H * pl.W, words = (size_t)pl.H * pl.WW;
     const int H = pl.H, W = pl.W;
     const lg_params& P = pl.P;
-    if (h->orient && !h->orient_inline) LG_HIP(h, hipStreamWaitEvent(s, h->ev_orient, 0));   // fp_dev was written on the side stream
+    if (h->orient) LG_HIP(h, hipStreamWaitEvent(s, h->ev_orient, 0));   // fp_dev was written on the side stream
     if (h->opt_side_tail) LG_HIP(h, hipStreamWaitEvent(s, h->ev_side, 0));  // maxfix (d_out border) and the stem bits
     if (upload_fp) LG_HIP(h, hipMemcpyAsync(h->fp_dev + off, h->fp_host + off, sizeof(LgFrameParams) * n, hipMemcpyHostToDevice, s));
     LgFinalArgs a;
@@ -768,7 +747,6 @@ int lg_score_maps(lg_handle h, const float* depth, const uint8_t* mask, int B, i
             pl.maps[i] = h->ws_maps[i];
         }
     if (!pl.valid) pl.valid = h->ws_valid;
-    h->orient_inline = false;
     rc = enq_prep(h, pl, 0, B, s, h->ev_prep);
     if (rc) return rc;
     rc = enq_dt(h, pl, 0, B, s);
@@ -1121,9 +1099,6 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         hipEventRecord(tev[0], s);
     }
     // bit rows of the whole batch first (one short kernel) so the host never waits behind a distance sweep
-    // (see below: the call runs through on the device orientation's results; up to 32 frames the kernel sits on the caller's stream)
-    const bool spec = h->orient != nullptr && !h->opt_orient_sync;
-    h->orient_inline = spec && !piped && B <= 32 && h->opt_subbatch == 0;
     rc = enq_prep(h, pl, 0, B, sD[0], h->ev_prep);
     if (rc) return rc;
     if (piped) LG_HIP(h, hipStreamWaitEvent(sD[1], h->ev_prep, 0));
@@ -1136,22 +1111,10 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
     if (trace && !piped) hipEventRecord(tev[1], s);   // after the sweeps
     const double t_enq1 = now();
     const double t_copy = now();
-    // theta per frame.  The device kernel's results are used where they are (the plane kernel waits for them on its stream); only
-    // when it hands a frame back to the host analysis (more runs than its scratch holds: h_status) does the host have to know --
-    // and waiting for that before the plane kernel is enqueued put a host round trip (~40 us) on the critical path of every small
-    // call.  So the call runs through on the device results, looks at the status words after its final synchronisation, and in the
-    // rare case of a handed-back frame analyses it on the host and runs the part from the plane kernel on a second time.
-    // LG_ORIENT_SYNC=1: wait first, as before (also: no device orientation at all).
     bool upload_fp = true;
-    if (spec) upload_fp = false;
-    else {
-        rc = finish_orient(h, pl, 0, B, &upload_fp);
-        if (rc) return rc;
-    }
+    rc = finish_orient(h, pl, 0, B, &upload_fp);   // theta per frame: device results (or host analysis) while the sweeps run
+    if (rc) return rc;
     const double t_orient = now();
-    double t_enq2 = 0.0, t_sync = 0.0;
-    auto tail = [&](bool upload_fp) -> int {
-    int rc = LG_OK;
     for (int k = 0; k < nsub; k++) {
         const int off = k * SB, n = std::min(SB, B - off);
         if (piped) LG_HIP(h, hipStreamWaitEvent(sM, EV(k, 2), 0));
@@ -1195,30 +1158,11 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
         ProfScope ps(h, "finish", s);
         lg_launch_finish(fa, s);
     }
-    if (h->orient_inline && !upload_fp) {   // (first pass: the orientation's results and status words for the check below)
-        rc = enq_orient_results(h, 0, B, s);
-        if (rc) return rc;
-    }
     LG_HIP(h, hipMemcpyAsync(h->res_host, h->res_dev, sizeof(lg_grasp_result) * B, hipMemcpyDeviceToHost, s));
-    t_enq2 = now();
+    const double t_enq2 = now();
     LG_HIP(h, hipStreamSynchronize(s));
-    t_sync = now();
+    const double t_sync = now();
     LG_HIP(h, hipGetLastError());
-    return LG_OK;
-    };
-    rc = tail(upload_fp);
-    if (rc) return rc;
-    if (spec) {
-        LG_HIP(h, hipEventSynchronize(h->ev_orient));   // (reached long ago: the plane kernel waited for it)
-        bool handed_back = false;
-        for (int i = 0; i < B; i++) handed_back |= h->orient->h_status[i] != 0;
-        if (handed_back) {
-            rc = finish_orient(h, pl, 0, B, &upload_fp);   // host analysis of those frames into fp_host
-            if (rc) return rc;
-            rc = tail(true);
-            if (rc) return rc;
-        }
-    }
     memcpy(results, h->res_host, sizeof(lg_grasp_result) * B);
     if (trace && !piped) {
         float a[5] = {0};
