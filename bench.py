@@ -571,6 +571,19 @@ def main():
                 dm = torch.from_numpy(np.stack([labels_np[i % len(labels_np)] >= 1 for i in range(nd)]).astype(np.uint8)).to(dev)
                 dd = depths[:nd]
                 dsel.score_maps(dm, dd)
+                # which state of the part this leg sees: the headline's plane launch, timed right before it (2.6-2.7 ms per 256
+                # frames on a fresh part, 3.2-3.3 after ~30 s of load: tools/final_variance.sh)
+                try:
+                    lib.lg_profile_enable(sels[0]._h, 2)
+                    for _ in range(2):
+                        sels[0].select_grasp_points_batch(masks, depths)
+                    torch.cuda.synchronize(dev)
+                    n_s, ms_s = C.c_int(0), C.c_double(0.0)
+                    lib.lg_profile_read(sels[0]._h, b"final", C.byref(n_s), C.byref(ms_s))
+                    lib.lg_profile_enable(sels[0]._h, 0)
+                    state_ms = round(ms_s.value / max(1, n_s.value), 4)
+                except Exception as e_state:  # noqa: BLE001
+                    state_ms = f"not measured: {e_state}"
                 lib.lg_profile_enable(dsel._h, 2)
                 for _ in range(args.dense_steps):
                     dsel.score_maps(dm, dd)
@@ -602,6 +615,10 @@ def main():
                                          "bytes_per_px": FINAL_BYTES_PER_PX, "frames_per_launch": nd, "launches": n_l.value,
                                          "avg_ms": round(ms_l.value / max(1, n_l.value), 4),
                                          "masks": "labels >= 1 (all leaves, 20-30 % of the frame), LG_NO_SKIP=1",
+                                         "headline_final_ms_just_before": state_ms,
+                                         "part_state": "the headline's plane launch timed right before this leg: 2.6-2.7 ms per 256 "
+                                                       "frames = fresh part, 3.2-3.3 = warmed-up part (tools/final_variance.sh); this "
+                                                       "leg's fraction moves with it",
                                          "traffic_mix_ceiling_frac": ceiling,
                                          "traffic_mix_ceiling": "profiles/r02_ubench_stream_mix.txt: a kernel with only this "
                                                                 "path's loads and stores (2 reads + 7 float planes + 1 byte plane "
