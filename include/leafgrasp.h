@@ -197,6 +197,15 @@ int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B,
                     const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
                     lg_grasp_result* results, void* stream);
 
+/* lg_select_grasp on mask[b] = (labels[b] == leaf_ids[b]): the node's `optimal_mask = mask_tensor == optimal_leaf_id` followed
+   by select_grasp_point (scripts/leaf_grasp_node_v3.py:118-125) with the comparison folded into the library's first pass over
+   the frame.  labels [B][H][W] int16 DEVICE (the label image lg_leaf_select_batch reads), leaf_ids [B] HOST (an id no label
+   carries, e.g. INT32_MIN, gives that frame an empty mask and found = 0).  Everything else as lg_select_grasp; the node's mask
+   is a torch.bool tensor: set lg_params.mask_is_bool = 1 for its behaviour at the image border. */
+int lg_select_grasp_labels(lg_handle h, const float* depth, const int16_t* labels, const int32_t* leaf_ids, int B, int H, int W,
+                           const lg_params* p, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
+                           lg_grasp_result* results, void* stream);
+
 /* The node's result message of every frame (leaf_grasp_node_v3.py:170-176: "x,y,X,Y,Z[,pX,pY,pZ]", each number as Python's
    str() prints it -- the shortest decimal string of the float32 value as a double), '\n'-terminated, one line per frame in
    order, an empty line for a frame without a result.  buf: HOST, cap bytes (>= 256 per frame); *used = bytes written.

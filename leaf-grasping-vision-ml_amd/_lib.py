@@ -75,6 +75,8 @@ SYMBOLS = {
     "lg_cnn_forward": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
     "lg_select_grasp": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(LgParams),
                                   C.POINTER(_VP * LG_NUM_MAPS), _VP, C.POINTER(LgGraspResult), _VP]),
+    "lg_select_grasp_labels": (C.c_int, [_VP, _VP, _VP, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.POINTER(LgParams),
+                                         C.POINTER(_VP * LG_NUM_MAPS), _VP, C.POINTER(LgGraspResult), _VP]),
     "lg_leaf_stats": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(LgLeafStat), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32), _VP]),
     "lg_leaf_stats_batch": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,

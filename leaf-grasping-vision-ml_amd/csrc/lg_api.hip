@@ -49,6 +49,11 @@ struct lg_ctx {
     unsigned long long *bits = nullptr, *stem = nullptr, *tilekeys = nullptr;
     uint32_t* maxfix = nullptr;
     LgDtBatch* dt_batch = nullptr;   // search-or-sweeps sums of a batch (lg_bbox_kernel)
+    uint8_t* mask_ws = nullptr;      // lg_select_grasp_labels: the 0 / 1 mask it derives from the labels (grown on demand)
+    size_t mask_ws_cap = 0;
+    int32_t* ids_dev = nullptr;      //   and the frames' leaf ids (device / pinned host staging)
+    int32_t* ids_host = nullptr;
+    int ids_cap = 0;
     LgWin* win = nullptr;           // [B] sweep windows (lg_bbox_kernel)
     LgFrameParams* fp_dev = nullptr;
     LgFrameParams* fp_host = nullptr;        // pinned
@@ -386,6 +391,9 @@ int lg_destroy(lg_handle h) {
     delete h->pool;
     h->pool = nullptr;
     free_ws(h);
+    if (h->mask_ws) hipFree(h->mask_ws);
+    if (h->ids_dev) hipFree(h->ids_dev);
+    if (h->ids_host) hipHostFree(h->ids_host);
     lg_cnn_free(&h->cnn);
     lg_leaf_free(h->leaf);
     lg_leaf_prof_free(h->leaf_prof);
@@ -478,6 +486,7 @@ struct Plan {  // one call's geometry, parameters and plane pointers (absolute, 
     lg_params P;
     const float* depth;
     const uint8_t* mask;
+    const int16_t* labels = nullptr;   // lg_select_grasp_labels: mask (the handle's workspace) is written from these by the bit-row pass
     float* maps[LG_NUM_MAPS];
     uint8_t* valid;
 };
@@ -514,7 +523,11 @@ int enq_prep(lg_ctx* h, const Plan& pl, int off, int n, hipStream_t s, hipEvent_
     LG_HIP(h, hipMemsetAsync(h->maxfix + 2 * (size_t)off, 0, sizeof(uint32_t) * 2 * n, s));
     {
         ProfScope ps(h, "prep", s);
-        lg_launch_pack_bits(pl.mask + off * px, h->bits + off * words, n, pl.H, pl.W, pl.WW, s);
+        if (pl.labels)
+            lg_launch_pack_labels(pl.labels + off * px, h->ids_dev + off, h->mask_ws + off * px, h->bits + off * words, n, pl.H, pl.W,
+                                  pl.WW, s);
+        else
+            lg_launch_pack_bits(pl.mask + off * px, h->bits + off * words, n, pl.H, pl.W, pl.WW, s);
     }
     {
         ProfScope ps(h, "bbox", s);
@@ -1008,14 +1021,56 @@ int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void
     return LG_OK;
 }
 
+static int lg_select_grasp_impl(lg_handle h, const float* depth, const uint8_t* mask, const int16_t* labels, int B, int H, int W,
+                                const lg_params* pin, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
+                                lg_grasp_result* results, void* stream_);
+
 int lg_select_grasp(lg_handle h, const float* depth, const uint8_t* mask, int B, int H, int W, const lg_params* pin,
                     float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, lg_grasp_result* results, void* stream_) {
     if (!h) return LG_ERR_INVALID;
     LG_ENTER(h);
+    return lg_select_grasp_impl(h, depth, mask, nullptr, B, H, W, pin, out_maps, out_valid, results, stream_);
+}
+
+// lg_select_grasp on mask[b] = (labels[b] == leaf_ids[b]): the node's `optimal_mask = mask_tensor == optimal_leaf_id` followed by
+// select_grasp_point (leaf_grasp_node_v3.py:118-125), the comparison folded into the bit-row pass.
+int lg_select_grasp_labels(lg_handle h, const float* depth, const int16_t* labels, const int32_t* leaf_ids, int B, int H, int W,
+                           const lg_params* pin, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid, lg_grasp_result* results,
+                           void* stream_) {
+    if (!h) return LG_ERR_INVALID;
+    LG_ENTER(h);
+    if (!labels || !leaf_ids || B < 1 || H < 1 || W < 1) return fail(h, LG_ERR_INVALID, "lg_select_grasp_labels: null or empty input");
+    LG_HIP(h, hipSetDevice(h->device));
+    const size_t need = (size_t)B * H * W;
+    if (need > h->mask_ws_cap) {
+        if (h->mask_ws) { hipDeviceSynchronize(); hipFree(h->mask_ws); h->mask_ws = nullptr; h->mask_ws_cap = 0; }
+        if (hipMalloc((void**)&h->mask_ws, need) != hipSuccess) { (void)hipGetLastError(); return fail(h, LG_ERR_NOMEM, "lg_select_grasp_labels: mask workspace"); }
+        h->mask_ws_cap = need;
+    }
+    if (B > h->ids_cap) {
+        if (h->ids_dev) { hipDeviceSynchronize(); hipFree(h->ids_dev); h->ids_dev = nullptr; }
+        if (h->ids_host) { hipHostFree(h->ids_host); h->ids_host = nullptr; }
+        h->ids_cap = 0;
+        if (hipMalloc((void**)&h->ids_dev, sizeof(int32_t) * B) != hipSuccess ||
+            hipHostMalloc((void**)&h->ids_host, sizeof(int32_t) * B) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, LG_ERR_NOMEM, "lg_select_grasp_labels: id buffers");
+        }
+        h->ids_cap = B;
+    }
+    memcpy(h->ids_host, leaf_ids, sizeof(int32_t) * B);   // (the previous call on this handle has been synchronised: one call in flight)
+    LG_HIP(h, hipMemcpyAsync(h->ids_dev, h->ids_host, sizeof(int32_t) * B, hipMemcpyHostToDevice, (hipStream_t)stream_));
+    return lg_select_grasp_impl(h, depth, h->mask_ws, labels, B, H, W, pin, out_maps, out_valid, results, stream_);
+}
+
+static int lg_select_grasp_impl(lg_handle h, const float* depth, const uint8_t* mask, const int16_t* labels, int B, int H, int W,
+                                const lg_params* pin, float* const out_maps[LG_NUM_MAPS], uint8_t* out_valid,
+                                lg_grasp_result* results, void* stream_) {
     if (!results) return fail(h, LG_ERR_INVALID, "lg_select_grasp: results is null");
     Plan pl;
     int rc = make_plan(h, pl, depth, mask, B, H, W, pin, out_maps, out_valid, "lg_select_grasp");
     if (rc) return rc;
+    pl.labels = labels;
     const lg_params& P = pl.P;
     if (P.top_k < 1 || P.top_k > 64) return fail(h, LG_ERR_INVALID, "lg_select_grasp: top_k must be in [1,64]");
     hipStream_t s = (hipStream_t)stream_;

@@ -98,6 +98,9 @@ struct LgFinalArgs {
 
 // kernel launchers (lg_kernels.hip)
 void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, int H, int W, int WW, hipStream_t s);
+// mask[b] = labels[b] == ids[b] (0 / 1 bytes) and its bit rows in one pass (ids: DEVICE, one per frame)
+void lg_launch_pack_labels(const int16_t* labels, const int32_t* ids_dev, uint8_t* mask, unsigned long long* bits, int B, int H,
+                           int W, int WW, hipStream_t s);
 void lg_launch_export_rows(const unsigned long long* bits, const LgWin* wins, unsigned long long* dst_host_devptr, int B,
                            int H, int WW, hipStream_t s);
 void lg_launch_stem_bits(const unsigned long long* bits, unsigned long long* stem, int B, int H, int W, int WW,

@@ -172,6 +172,62 @@ void lg_launch_pack_bits(const uint8_t* mask, unsigned long long* bits, int B, i
     hipLaunchKernelGGL(lg_pack_bits_kernel, dim3(blocks), dim3(256), 0, s, mask, bits, H, W, WW, nwords);
 }
 
+// The node's `optimal_mask = mask_tensor == optimal_leaf_id` (leaf_grasp_node_v3.py:118) folded into the bit-row pass: labels
+// [B][H][W] int16 and one leaf id per frame in, the 0 / 1 byte mask (what the sweeps and the patch gather read) and the bit rows
+// out.  One pass over the labels instead of torch's comparison (labels in, mask out) + lg_pack_bits (mask in).  A lane takes 16
+// labels (two 16-byte loads), four adjacent lanes assemble a word; W % 16 == 0 (the launcher falls back otherwise).
+__global__ __launch_bounds__(256) void lg_pack_labels16_kernel(const int16_t* __restrict__ labels, const int32_t* __restrict__ ids,
+                                                               uint8_t* __restrict__ mask, unsigned long long* __restrict__ bits,
+                                                               int H, int W, int WW, long long nslots_total) {
+    const int slots_per_row = 4 * WW;
+    long long sid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;  // multiple of 4: a word's four slots stay in adjacent lanes
+    for (; sid < nslots_total; sid += stride) {
+        const long long row = sid / slots_per_row;
+        const int slot = (int)(sid - row * slots_per_row);
+        const int x = slot * 16;
+        unsigned b16 = 0;
+        if (x < W) {
+            const int id = ids[row / H];
+            const uint4 v0 = *reinterpret_cast<const uint4*>(labels + row * W + x);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(labels + row * W + x + 8);
+            const uint32_t w8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint32_t mb[4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const unsigned lo = (int)(int16_t)(w8[q] & 0xffffu) == id ? 1u : 0u, hi = (int)(int16_t)(w8[q] >> 16) == id ? 1u : 0u;
+                b16 |= (lo | (hi << 1)) << (2 * q);
+                const uint32_t two = lo | (hi << 8);
+                if (q & 1) mb[q >> 1] |= two << 16; else mb[q >> 1] = two;
+            }
+            *reinterpret_cast<uint4*>(mask + row * W + x) = make_uint4(mb[0], mb[1], mb[2], mb[3]);
+        }
+        unsigned long long word = (unsigned long long)b16 << (16 * (slot & 3));
+        word |= __shfl_xor(word, 1, 64);
+        word |= __shfl_xor(word, 2, 64);
+        if ((slot & 3) == 0) bits[row * WW + (slot >> 2)] = word;
+    }
+}
+__global__ __launch_bounds__(256) void lg_labels_mask_kernel(const int16_t* __restrict__ labels, const int32_t* __restrict__ ids,
+                                                             uint8_t* __restrict__ mask, long long px_per_frame, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        mask[i] = (int)labels[i] == ids[i / px_per_frame] ? 1 : 0;
+}
+void lg_launch_pack_labels(const int16_t* labels, const int32_t* ids_dev, uint8_t* mask, unsigned long long* bits, int B, int H,
+                           int W, int WW, hipStream_t s) {
+    if ((W & 15) == 0 && ((uintptr_t)labels & 15) == 0 && ((uintptr_t)mask & 15) == 0) {
+        const long long nslots = (long long)B * H * WW * 4;
+        long long blocks = (nslots + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(lg_pack_labels16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, labels, ids_dev, mask, bits, H, W, WW, nslots);
+        return;
+    }
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(lg_labels_mask_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, s, labels,
+                       ids_dev, mask, (long long)H * W, total);
+    lg_launch_pack_bits(mask, bits, B, H, W, WW, s);
+}
+
 // Export of the bits the host needs -- the rows and 64-bit words of each frame's bounding box only (a leaf spans a third
 // of the frame in each direction: ~10x less PCIe traffic than the whole batch) -- by posted 8-byte writes into the pinned host image,
 // which keeps its [B][H][WW] layout; rows outside the bounding box are all zero and never read by the host.

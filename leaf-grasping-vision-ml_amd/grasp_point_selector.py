@@ -298,6 +298,35 @@ class GraspPointSelector:
             return out, {n: maps[i] for i, n in enumerate(MAP_NAMES)}, valid
         return out
 
+    def select_grasp_points_for_leaves(self, label_tensors, leaf_ids, depth_tensors, image_processor=None):
+        """select_grasp_points_batch(label_tensors == leaf_ids[:, None, None], depth_tensors) -- the node's `optimal_mask =
+        mask_tensor == optimal_leaf_id` and select_grasp_point (leaf_grasp_node_v3.py:118-125) -- with the comparison folded into
+        the library's first pass over the frames (lg_select_grasp_labels).  label_tensors: [B,H,W] int16 on this device; leaf_ids:
+        B ints, None for a frame without a leaf (the node does not call select_grasp_point for it: its triple is (None, None,
+        None)).  The mask counts as the torch.bool tensor the node passes."""
+        lab = label_tensors
+        if not (torch.is_tensor(lab) and lab.dtype == torch.int16 and lab.is_cuda and lab.dim() == 3 and lab.is_contiguous()):
+            raise ValueError("label_tensors must be a contiguous [B,H,W] int16 tensor on the device")
+        d = depth_tensors.to(self.device, torch.float32).contiguous()
+        if d.shape != lab.shape:
+            raise ValueError(f"labels {tuple(lab.shape)} and depth {tuple(d.shape)} must both be [B,H,W]")
+        B, H, W = lab.shape
+        p = self._sync_params(image_processor)
+        p.mask_is_bool = 1
+        ids = (C.c_int32 * B)(*[(-(1 << 30)) if i is None else int(i) for i in leaf_ids])
+        res = (LgGraspResult * B)()
+        with torch.cuda.device(self.device):
+            check(self._h, lib.lg_select_grasp_labels(self._h, d.data_ptr(), lab.data_ptr(), ids, B, H, W, C.byref(p), None, None, res,
+                                                      self._stream()), "lg_select_grasp_labels")
+        for b, i in enumerate(leaf_ids):   # the node never calls select_grasp_point for a frame without a leaf (:113-116)
+            if i is None:
+                res[b].found = 0
+        a = np.frombuffer(res, dtype=_RESULT_DTYPE, count=B)
+        cols = [a[n].tolist() for n in ("found", "x", "y", "X", "Y", "Z", "has_pre", "pX", "pY", "pZ")]
+        self.last_results = res
+        return [((x, y), (X, Y, Z), (pX, pY, pZ) if hp else None) if f else (None, None, None)
+                for f, x, y, X, Y, Z, hp, pX, pY, pZ in zip(*cols)]
+
     def select_grasp_point(self, leaf_mask, depth_tensor, image_processor=None, pcl_data=None):
         """Select optimal grasp point using combined traditional and ML approach (reference :184)."""
         try:

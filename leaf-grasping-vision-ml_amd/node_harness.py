@@ -144,14 +144,20 @@ class LeafGraspHarness:
         keep = [b for b in range(B) if ids[b] is not None]
         if not keep:
             return
-        idt = torch.tensor([ids[b] for b in keep], dtype=mask_t.dtype, device=self.device).reshape(-1, 1, 1)
-        if len(keep) == B:
-            optimal, dep = mask_t == idt, depth_t
+        if mask_t.dtype == torch.int16 and mask_t.is_contiguous() and depth_t.is_contiguous():
+            # the comparison inside the library's first pass over the labels (frames without a leaf get an empty mask there)
+            self.grasp_selector.select_grasp_points_for_leaves(mask_t, ids, depth_t, image_processor=self.image_processor)
+            rows = range(B)
         else:
-            sel = torch.tensor(keep, device=self.device)
-            optimal, dep = mask_t.index_select(0, sel) == idt, depth_t.index_select(0, sel)
-        self.grasp_selector.select_grasp_points_batch(optimal, dep, image_processor=self.image_processor)
+            idt = torch.tensor([ids[b] for b in keep], dtype=mask_t.dtype, device=self.device).reshape(-1, 1, 1)
+            if len(keep) == B:
+                optimal, dep = mask_t == idt, depth_t
+            else:
+                sel = torch.tensor(keep, device=self.device)
+                optimal, dep = mask_t.index_select(0, sel) == idt, depth_t.index_select(0, sel)
+            self.grasp_selector.select_grasp_points_batch(optimal, dep, image_processor=self.image_processor)
+            rows = keep
         # the messages of the whole chunk in one native call (format_result's strings, character for character: Python's float
         # repr costs 0.24 ms per 128 frames -- a third of a millisecond the device waits for)
-        for b, line in zip(keep, self.format_results(self.grasp_selector.last_results, len(keep))):
+        for b, line in zip(rows, self.format_results(self.grasp_selector.last_results, len(rows))):
             out[offset + b] = line

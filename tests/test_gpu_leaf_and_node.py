@@ -607,3 +607,30 @@ def test_bench_two_ranks_one_device(tmp_path):
     # whole-job value: 2 ranks x batch x steps frames over the (max over ranks) time
     assert res["value"] == pytest.approx(2 * batch * steps / (res["ms_per_step"] * steps * 1e-3), rel=2e-3)
     assert "cpu_baseline" not in res and "roofline" in res      # the CPU leg is rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("shape", [(360, 480), (270, 363)])
+def test_grasp_points_for_leaves_equal_the_masks_path(L, shape):
+    """lg_select_grasp_labels -- the node's `optimal_mask = mask_tensor == optimal_leaf_id` (leaf_grasp_node_v3.py:118) folded
+    into the library's first pass over the frame -- against the comparison done by torch and select_grasp_points_batch on the
+    bool masks: the same triples, frame by frame, for a width the 16-label vector pass takes and one it does not; a frame
+    without a leaf id comes back as (None, None, None) (the node skips it), one whose id no pixel carries as the masks path's
+    answer for an empty mask."""
+    H, W = shape
+    frames = [O.synthetic_scene(H, W, 90 + i) for i in range(5)]
+    labels = torch.from_numpy(np.stack([f[0] for f in frames]).astype(np.int16)).cuda()
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    sel = L.GraspPointSelector("cuda:0", load_model=False)
+    sel.set_camera_params(frames[0][2])
+    sel.set_cnn_state_dict(O.cnn_closed_form_params(seed=0))
+    ids = [1, 2, None, 1, 31000]
+    got = sel.select_grasp_points_for_leaves(labels, ids, depth)
+    idt = torch.tensor([1, 2, -5, 1, 31000], dtype=torch.int16, device="cuda").reshape(-1, 1, 1)
+    want = sel.select_grasp_points_batch(labels == idt, depth)
+    assert got[2] == (None, None, None) and got[0][0] is not None
+    assert [g for b, g in enumerate(got) if b != 2] == [w for b, w in enumerate(want) if b != 2]   # (an empty mask takes the reference's fall-through)
+    # and again on the same handle with other ids (the id buffer and the mask workspace are reused)
+    ids2 = [2, 1, 1, None, 3]
+    idt2 = torch.tensor([2, 1, 1, -5, 3], dtype=torch.int16, device="cuda").reshape(-1, 1, 1)
+    got2, want2 = sel.select_grasp_points_for_leaves(labels, ids2, depth), sel.select_grasp_points_batch(labels == idt2, depth)
+    assert got2[3] == (None, None, None) and got2[:3] + got2[4:] == want2[:3] + want2[4:]
