@@ -202,8 +202,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
         s_acc[i].sum_depth = 0.0; s_acc[i].sum_ray = 0.0; s_acc[i].border = 0; s_acc[i].kmax = 0; s_acc[i].nkmin = 0;
     }
     __syncthreads();
+    // A wave's 64 runs form a TILE of 64 x 16 pixels (4 runs across, 16 rows), not 1024 pixels of one row: every wave that meets
+    // a leaf pixel walks the whole per-pixel loop for all its lanes (61 % of the SIMDs' vector issue cycles went there,
+    // profiles/r04_leaf_pmc.txt), and a 1024-pixel strip meets a leaf in most rows of the image while a tile only does where one is.
     const int runs_per_row = (W + LGL_RUN - 1) / LGL_RUN;
-    const long long nruns = (long long)H * runs_per_row;
+    const int tiles_x = (runs_per_row + 3) / 4, tiles_y = (H + 15) / 16;
+    const long long nruns = (long long)tiles_x * tiles_y * 64;
     const double f2 = (double)f * (double)f;
     const bool vec = run_vec_ok(lab, depth, W);
     const int lane = threadIdx.x & 63;
@@ -214,11 +218,14 @@ __global__ __launch_bounds__(256) void k_accumulate(const int16_t* __restrict__ 
         int y = 0, x0 = 0, x1 = 0;
         bool any = false;
         if (r < nruns) {
-            y = (int)(r / runs_per_row); x0 = (int)(r % runs_per_row) * LGL_RUN;
+            const long long tile = r >> 6;
+            const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
+            const int xi = 4 * tx + (lane & 3);
+            y = 16 * ty + (lane >> 2); x0 = xi * LGL_RUN;
             x1 = min(x0 + LGL_RUN, W);
-            any = load_run(lab, W, y, x0, x1, vec, ids);
+            if (y < H && xi < runs_per_row) any = load_run(lab, W, y, x0, x1, vec, ids);
         }
-        if (__ballot(any) == 0ull) continue;                 // wave-uniform: no leaf pixel in these 1024 pixels
+        if (__ballot(any) == 0ull) continue;                 // wave-uniform: no leaf pixel in this tile
         if (any) {
             load_run_depth(depth, W, y, x0, x1, vec, dv);
         } else {
@@ -1107,8 +1114,9 @@ int lg_leaf_run_batch(LgLeafWs*& w, const int16_t* labels, const float* depth, i
     static const int gx_budget = getenv("LG_LEAF_GX") ? atoi(getenv("LG_LEAF_GX")) : 2048;   // workgroups per batch of the streaming passes
     const int gx = std::max(16, std::min(256, gx_budget / B));
     const dim3 grid(gx, B);
-    // list segments: workgroup x of a frame meets at most ceil(runs / (gx * 256)) steps of 256 runs of 16 pixels
-    const long long nruns_acc = (long long)H * ((W + LGL_RUN - 1) / LGL_RUN);
+    // list segments: workgroup x of a frame meets at most ceil(runs / (gx * 256)) steps of 256 runs of 16 pixels (k_accumulate
+    // walks tiles of 4 x 16 runs: the run count is the padded one)
+    const long long nruns_acc = (long long)(((W + LGL_RUN - 1) / LGL_RUN + 3) / 4) * ((H + 15) / 16) * 64;
     const unsigned segcap = (unsigned)((nruns_acc + (long long)gx * 256 - 1) / ((long long)gx * 256)) * 256u * LGL_RUN;
     const size_t comp_stride = (size_t)segcap * gx;          // <= H * W + gx * 4096 entries per frame
     static const int ablate = getenv("LG_LEAF_ABLATE") ? atoi(getenv("LG_LEAF_ABLATE")) : 0;   // timing experiments only (wrong results)
