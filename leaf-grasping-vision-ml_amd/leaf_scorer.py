@@ -183,14 +183,18 @@ class OptimalLeafSelector:
         except Exception as e:  # noqa: BLE001
             logerr(f"Error in leaf selection: {str(e)}")
             return [None] * len(mask_tensors)
+        # (one conversion per array: a ctypes element access per frame and tall leaf cost 0.1 ms per 128 frames)
+        ids_l = np.frombuffer(ids, dtype=np.int32, count=B).tolist()
+        nt_l = np.frombuffer(n_tall, dtype=np.int32, count=B).tolist()
+        tall_l = np.frombuffer(tall, dtype=np.int32, count=B * tall_cap).reshape(B, tall_cap).tolist()
         out, tall_b = [], []
-        for b in range(B):
-            if ids[b] == -2 or n_tall[b] > tall_cap:   # many labels / leaves: the general path for this frame
+        for b, (i, nt) in enumerate(zip(ids_l, nt_l)):
+            if i == -2 or nt > tall_cap:   # many labels / leaves: the general path for this frame
                 out.append(self.select_optimal_leaf(lab[b], dep[b]))
                 tall_b.append(self.get_tall_leaves() if out[-1] is not None else [])
                 continue
-            out.append(int(ids[b]) if ids[b] >= 0 else None)
-            tall_b.append([int(tall[b * tall_cap + k]) for k in range(n_tall[b])] if ids[b] >= 0 else [])
+            out.append(i if i >= 0 else None)
+            tall_b.append(tall_l[b][:nt] if i >= 0 else [])
         self._tall_leaves_batch = tall_b
         return out
 
