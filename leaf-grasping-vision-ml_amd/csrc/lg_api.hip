@@ -1014,6 +1014,7 @@ int lg_cnn_forward(lg_handle h, const float* patches, int N, float* logits, void
     hipStream_t s = (hipStream_t)stream_;
     LG_HIP(h, hipSetDevice(h->device));
     std::string err;
+    if (lg_cnn_take_error(&h->cnn)) return fail(h, LG_ERR_HIP, "lg_cnn_forward: a split item of the previous forward did not receive its parts");
     ProfScope ps(h, "cnn", s);
     int rc = lg_cnn_run(&h->cnn, patches, false, N, logits, s, &err);
     if (rc) return fail(h, rc, err.c_str());
@@ -1218,6 +1219,7 @@ static int lg_select_grasp_impl(lg_handle h, const float* depth, const uint8_t* 
     LG_HIP(h, hipStreamSynchronize(s));
     const double t_sync = now();
     LG_HIP(h, hipGetLastError());
+    if (use_cnn && lg_cnn_take_error(&h->cnn)) return fail(h, LG_ERR_HIP, "lg_select_grasp: a split CNN item did not receive its parts");
     memcpy(results, h->res_host, sizeof(lg_grasp_result) * B);
     if (trace && !piped) {
         float a[5] = {0};

@@ -38,6 +38,8 @@ struct LgCnn {
     float* zeros = nullptr;       // 4096 zero floats
     float* kpart = nullptr;       // lg_wino4_kernel: partial accumulators of items split along the input channels, one slot per workgroup
     unsigned* kflag = nullptr;    //   and the counters of the parts that have arrived
+    unsigned* kerr_host = nullptr;   // set by a split item whose parts did not arrive (pinned host word; kerr_dev = its device address)
+    unsigned* kerr_dev = nullptr;
     int wino_mask = 0x3f;         // bit L = layer L on Winograd (LG_CNN_DIRECT / LG_CNN_WINO_MASK at load time; bits 1..5: standard encoder only)
     int capN = 0;
 };
@@ -48,3 +50,5 @@ void lg_cnn_free(LgCnn* c);
 // gather writes directly; lg_cnn_halo_patch_floats() floats per patch)
 int lg_cnn_run(LgCnn* c, const float* patches, bool haloed_in, int N, float* logits, hipStream_t s, std::string* err);
 size_t lg_cnn_halo_patch_floats(void);
+// after a synchronisation of the stream a forward ran on: true (once) if a split item of it gave up waiting for its parts
+bool lg_cnn_take_error(LgCnn* c);

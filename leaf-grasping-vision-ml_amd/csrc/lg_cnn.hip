@@ -575,7 +575,7 @@ __device__ __forceinline__ void lg_lds_wait2(lg_f32x4& a, lg_f32x4& b) {
 template <int CIN, int COUT, int WI, bool POOL, bool OUT_HALO, bool COB_MAJOR, bool SPLIT>
 __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__ in, const float* __restrict__ U4,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N, int ntb,
-                                                       float* __restrict__ kpart, unsigned* __restrict__ kflag) {
+                                                       float* __restrict__ kpart, unsigned* __restrict__ kflag, unsigned* __restrict__ kerr) {
     constexpr int KC = 4;
     constexpr int TC = WI / 4, TP = TC * TC;               // tile columns, tiles per patch
     constexpr int PB = TP >= 32 ? 1 : 32 / TP;             // patches per item
@@ -1081,11 +1081,16 @@ __global__ __launch_bounds__(512) void lg_wino4_kernel(const float* __restrict__
                 }
                 if (t == 0) {
                     // (the parts have lower workgroup indices on this XCD: dispatched before this one, they are running or done.
-                    //  Should that ever not hold, the launch fails after ~0.5 s instead of waiting for ever.)
+                    //  Should that ever not hold, the wait ends after ~0.5 s, the item is stored from what has arrived and the word
+                    //  at kerr -- host memory the library looks at after its next synchronisation -- makes that call fail.  No trap: a
+                    //  faulting kernel can cost the whole node a reset.)
                     unsigned spins = 0;
                     while (__hip_atomic_load(&kflag[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(P - 1)) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 22)) __builtin_trap();
+                        if (++spins > (1u << 22)) {
+                            if (kerr) __hip_atomic_store(kerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
                     }
                     __hip_atomic_store(&kflag[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch; every part has counted itself in)
                 }
@@ -1299,7 +1304,7 @@ static int lg_w4_num_cu() {
 constexpr size_t LG_W4_KPART_FLOATS = 16 * 512 * 4;   // partial outputs of one workgroup (lg_wino4_kernel, split items)
 
 bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const float* in, const float* U4, const float* bias,
-                     float* out, int N, int max_cus, float* kpart, unsigned* kflag, hipStream_t s) {
+                     float* out, int N, int max_cus, float* kpart, unsigned* kflag, unsigned* kerr, hipStream_t s) {
     const int tp = (wi / 4) * (wi / 4);
     const int ntb = tp >= 32 ? N * (tp / 32) : (N + 32 / tp - 1) / (32 / tp);
     // persistent: one 512-thread workgroup per CU (140-156 KB of LDS each)
@@ -1324,11 +1329,11 @@ bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const 
         constexpr bool CM = 36LL * CI * CO * 4 > 3 * 1024 * 1024;                                                     \
         constexpr bool CAN = CI >= 128;   /* (cin / 4 * 7 / 8 >= 26) */                                              \
         if (out_halo) {                                                                                               \
-            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
-            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag, kerr); \
+            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, true, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag, kerr); \
         } else {                                                                                                      \
-            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
-            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag); \
+            if (CAN && split) hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, CAN>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag, kerr); \
+            else hipLaunchKernelGGL((lg_wino4_kernel<CI, CO, W_, P_, false, CM, false>), dim3(grid), dim3(512), 0, s, in, U4, bias, out, N, ntb, kpart, kflag, kerr); \
         }                                                                                                             \
         return true;                                                                                                  \
     }
@@ -1340,6 +1345,12 @@ bool launch_wino4_rt(int cin, int cout, int wi, bool pool, bool out_halo, const 
 
 }  // namespace
 
+bool lg_cnn_take_error(LgCnn* c) {
+    if (!c->kerr_host || !*(volatile unsigned*)c->kerr_host) return false;
+    *c->kerr_host = 0;
+    return true;
+}
+
 void lg_cnn_free(LgCnn* c) {
     auto F = [](float*& p) { if (p) hipFree(p); p = nullptr; };
     for (int i = 0; i < 8; i++) { F(c->wconv[i]); F(c->bconv[i]); F(c->uwino[i]); F(c->uwino4[i]); F(c->act[i]); }
@@ -1347,6 +1358,7 @@ void lg_cnn_free(LgCnn* c) {
     for (int i = 0; i < 4; i++) { F(c->fcw[i]); F(c->fcb[i]); }
     F(c->in_halo); F(c->zeros); F(c->kpart);
     if (c->kflag) { hipFree(c->kflag); c->kflag = nullptr; }
+    if (c->kerr_host) { hipHostFree(c->kerr_host); c->kerr_host = nullptr; c->kerr_dev = nullptr; }
     c->capN = 0;
     c->loaded = false;
 }
@@ -1543,6 +1555,14 @@ static int ensure_act(LgCnn* c, int N, hipStream_t s, std::string* err) {
             *err = "lg_cnn_forward: workspace allocation failed";
             return LG_ERR_NOMEM;
         }
+        // the word a split item sets when its parts do not arrive: pinned host memory the kernels write directly (no mapping: no word)
+        if (hipHostMalloc((void**)&c->kerr_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+            *c->kerr_host = 0;
+            if (hipHostGetDevicePointer((void**)&c->kerr_dev, c->kerr_host, 0) != hipSuccess) c->kerr_dev = nullptr;
+        } else {
+            (void)hipGetLastError();
+            c->kerr_host = nullptr;
+        }
     }
     if (N <= c->capN) return LG_OK;
     hipStreamSynchronize(s);
@@ -1594,7 +1614,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
     }
     // layer 0: the F(4x4,3x3) kernel on 12 input planes (3 chunks); the direct 9-channel kernel with LG_CNN_DIRECT / _F23 / mask bit 0 clear
     if (!c->use_f23 && (c->wino_mask & 1) &&
-        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, c->max_cus, c->kpart, c->kflag, s)) {
+        launch_wino4_rt(12, c->layers[0].coutp, 32, false, true, x, c->uwino4[0], c->bconv[0], c->act[0], N, c->max_cus, c->kpart, c->kflag, c->kerr_dev, s)) {
         // (a shape the F(4x4) table lacks falls through to the direct kernel instead of leaving act[0] unwritten)
     } else if (c->layers[0].coutp == 64) launch_conv0<64>(x, c, c->act[0], N, s);
     else launch_conv0<128>(x, c, c->act[0], N, s);
@@ -1606,7 +1626,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         const RtLayer& l = c->layers[L];                                                                            \
         if (!(wmask & (1 << L))) launch_conv<L, KC, PP, CP>(cur, c, c->act[L], N, s);                               \
         else if (c->use_f23) launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino[L], c->bconv[L], c->act[L], N, s); \
-        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, s); \
+        else launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L != 5, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, c->kerr_dev, s); \
         cur = c->act[L];                                                                                            \
     } while (0)
         LG_LAYER(1, 8, 4, 1);   // 64 -> 64, pool -> 16x16
@@ -1619,7 +1639,7 @@ static int lg_cnn_run_slice(LgCnn* c, const float* patches, bool haloed_in, int 
         for (int L = 1; L < c->n_layers; L++) {
             const RtLayer& l = c->layers[L];
             const bool okl = c->use_f23 ? launch_wino_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino[L], c->bconv[L], c->act[L], N, s)
-                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, s);
+                                        : launch_wino4_rt(l.cinp, l.coutp, l.wi, l.pool, L + 1 < c->n_layers, cur, c->uwino4[L], c->bconv[L], c->act[L], N, c->max_cus, c->kpart, c->kflag, c->kerr_dev, s);
             if (!okl) {
                 *err = "lg_cnn_forward: unsupported layer shape";
                 return LG_ERR_UNSUPPORTED;
